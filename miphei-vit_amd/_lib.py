@@ -1,0 +1,62 @@
+"""ctypes binding of libmiphei_hip.so (C-ABI declared in include/miphei_hip.h).
+
+The product path has no fallback: if the library is missing or a symbol is absent this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiphei_hip.so")
+
+# enum mvit_epilogue
+EPI_STORE, EPI_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_STATS, EPI_DSWIGLU, EPI_DGELU = range(8)
+OUT_F32, ATOMIC = 1, 2
+A_DENSE, A_CONV3, A_CONV3_T = 0, 1, 2
+
+vp, ci, cf, cd = C.c_void_p, C.c_int, C.c_float, C.c_double
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp), ("A2", vp), ("B2", vp), ("bias", vp), ("gamma", vp),
+        ("aux", vp), ("pos", vp), ("stats", vp),
+        ("M", ci), ("N", ci), ("K", ci), ("K2", ci),
+        ("lda", ci), ("ldb", ci), ("ldc", ci), ("lda2", ci), ("ldb2", ci), ("ldaux", ci),
+        ("epi", ci), ("flags", ci), ("ksplit", ci), ("amode", ci),
+        ("conv_H", ci), ("conv_W", ci), ("conv_C", ci), ("conv_ld", ci), ("conv_OH", ci), ("conv_OW", ci),
+        ("conv_stride", ci),
+        ("patch_P", ci), ("patch_ntok", ci), ("patch_prefix", ci),
+        ("nslots", ci),
+    ]
+
+
+# name -> argtypes (restype is always int); mirrors include/miphei_hip.h
+SIGNATURES = {
+    "mvit_gemm_bf16": [C.POINTER(GemmArgs), vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library once; fail loudly when it is missing (no CPU/PyTorch fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The MI355X path has no fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")

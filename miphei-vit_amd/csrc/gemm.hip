@@ -1,0 +1,26 @@
+// Dispatcher of the bf16 MFMA GEMM / implicit-GEMM convolution (kernel in gemm_kernel.hpp).
+#include "gemm_kernel.hpp"
+
+extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
+  using namespace mvit_gemm;
+  if (!args) return MVIT_EINVAL;
+  const mvit_gemm_args& a = *args;
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MVIT_EINVAL;
+  if ((a.K & 7) || (a.ldb & 7)) return MVIT_EINVAL;
+  if (a.amode == MVIT_A_DENSE && (a.lda & 7)) return MVIT_EINVAL;
+  if (a.amode != MVIT_A_DENSE && ((a.conv_C & 7) || (a.conv_ld & 7) || a.K != 9 * a.conv_C || a.A2)) return MVIT_EINVAL;
+  if (a.A2 && ((a.K2 & 7) || (a.lda2 & 7) || (a.ldb2 & 7) || !a.B2)) return MVIT_EINVAL;
+  if (a.ksplit > 1 && !(a.flags & MVIT_ATOMIC)) return MVIT_EINVAL;
+  if (a.epi == MVIT_EPI_STATS && (!a.stats || a.nslots <= 0)) return MVIT_EINVAL;
+  if ((a.epi == MVIT_EPI_DSWIGLU || a.epi == MVIT_EPI_DGELU) && !a.aux) return MVIT_EINVAL;
+  if (a.epi == MVIT_EPI_PATCH && (!a.pos || a.patch_P <= 0)) return MVIT_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool dense = a.amode == MVIT_A_DENSE;
+  if (a.epi == MVIT_EPI_SWIGLU) {
+    if ((a.N % 128) || !dense) return MVIT_EINVAL;
+    return launch_dense<128, 128, 2, 2>(a, s);
+  }
+  if (a.N % 128 == 0 || a.N >= 256) return dense ? launch_dense<128, 128, 2, 2>(a, s) : launch_conv<128, 128, 2, 2>(a, s);
+  if (a.N > 32) return dense ? launch_dense<128, 64, 2, 2>(a, s) : launch_conv<128, 64, 2, 2>(a, s);
+  return dense ? launch_dense<128, 32, 4, 1>(a, s) : launch_conv<128, 32, 4, 1>(a, s);
+}

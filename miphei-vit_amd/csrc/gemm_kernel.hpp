@@ -1,0 +1,367 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   C[M,N] = A[M,K] * B[N,K]^T (+ A2 * B2^T)      f32 accumulate on v_mfma_f32_32x32x16_bf16
+//
+// Structure: 256 threads = 4 wavefronts (64 lanes each), BMxBNx64 block tile, operands staged
+// global -> registers -> LDS (issue loads for tile t+1 before the MFMAs of tile t, write them after:
+// HBM latency hides under the matrix pipe), two LDS buffers, one barrier per K-step.  LDS rows are
+// 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row>>1)&7 so that every
+// ds_read_b128 lane group touches 16 distinct 16-byte slots (conflict-free, MI355X LDS banking).
+// The A operand loader is either dense or a 3x3 window gather from an NHWC activation (implicit GEMM
+// convolution, forward and adjoint), so the decoder convolutions run on the same mainloop.
+// Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles.
+#pragma once
+#include "common.hpp"
+#include "../../include/miphei_hip.h"
+
+namespace mvit_gemm {
+
+constexpr int BK = 64;
+
+struct ConvRow {
+  int b, y, x;
+  bool ok;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+
+  // ---- XCD-aware tile mapping (bijective for any grid size)
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = gridDim.x;
+  int wg;
+  {
+    const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tile_m = wg % tiles_m, tile_n = wg / tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- K range (split-K over blockIdx.z)
+  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
+  const int nk = nk1 + nk2;
+  int t_begin = 0, t_end = nk;
+  if (p.ksplit > 1) {
+    const int per = (nk + p.ksplit - 1) / p.ksplit;
+    t_begin = blockIdx.z * per;
+    t_end = min(nk, t_begin + per);
+    if (t_begin >= t_end) return;
+  }
+
+  const bf16_t* __restrict__ Ap = (const bf16_t*)p.A;
+  const bf16_t* __restrict__ Bp = (const bf16_t*)p.B;
+  const bf16_t* __restrict__ A2p = (const bf16_t*)p.A2;
+  const bf16_t* __restrict__ B2p = (const bf16_t*)p.B2;
+
+  const int c8 = tid & 7;       // 16-byte chunk inside the 64-wide K slice
+  const int row_base = tid >> 3;  // 0..31, +32 per chunk index
+
+  ConvRow crow[A_CH];
+  if (AMODE != MVIT_A_DENSE) {
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int gm = m0 + row_base + 32 * j;
+      crow[j].ok = gm < p.M;
+      const int g = crow[j].ok ? gm : 0;
+      crow[j].x = g % p.conv_OW;
+      const int t = g / p.conv_OW;
+      crow[j].y = t % p.conv_OH;
+      crow[j].b = t / p.conv_OH;
+    }
+  }
+
+  uint4 ra[A_CH], rb[B_CH];
+
+  auto load_tile = [&](int t) {
+    const bool ext = t >= nk1;
+    const int k0 = (ext ? t - nk1 : t) * BK + c8 * 8;
+    const int klim = ext ? p.K2 : p.K;
+    const bool kok = k0 < klim;
+    // ---- A
+    if (AMODE == MVIT_A_DENSE || ext) {
+      const bf16_t* src = ext ? A2p : Ap;
+      const int ld = ext ? p.lda2 : p.lda;
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        const int gm = m0 + row_base + 32 * j;
+        if (kok && gm < p.M)
+          ra[j] = *(const uint4*)(src + (size_t)gm * ld + k0);
+        else
+          ra[j] = make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      const int tap = k0 / p.conv_C, ch = k0 - tap * p.conv_C;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        int iy, ix;
+        bool ok = kok && crow[j].ok;
+        if (AMODE == MVIT_A_CONV3) {
+          iy = crow[j].y * p.conv_stride + ky - 1;
+          ix = crow[j].x * p.conv_stride + kx - 1;
+        } else {
+          const int ty = crow[j].y + 1 - ky, tx = crow[j].x + 1 - kx;
+          ok = ok && ty >= 0 && tx >= 0;
+          iy = ty / p.conv_stride;
+          ix = tx / p.conv_stride;
+          ok = ok && (iy * p.conv_stride == ty) && (ix * p.conv_stride == tx);
+        }
+        ok = ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W;
+        if (ok)
+          ra[j] = *(const uint4*)(Ap + ((size_t)(crow[j].b * p.conv_H + iy) * p.conv_W + ix) * p.conv_ld + ch);
+        else
+          ra[j] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    // ---- B
+    {
+      const bf16_t* src = ext ? B2p : Bp;
+      const int ld = ext ? p.ldb2 : p.ldb;
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j) {
+        const int gn = n0 + row_base + 32 * j;
+        if (kok && gn < p.N)
+          rb[j] = *(const uint4*)(src + (size_t)gn * ld + k0);
+        else
+          rb[j] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* a = smem + buf * BUF_BYTES;
+    char* b = a + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int row = row_base + 32 * j;
+      *(uint4*)(a + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      const int row = row_base + 32 * j;
+      *(uint4*)(b + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31, frag_half = lane >> 5;
+
+  load_tile(t_begin);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
+    if (more) load_tile(t + 1);
+    const char* a = smem + cur * BUF_BYTES;
+    const char* b = a + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 fa[TM], fb[TN];
+      const int ch = s * 2 + frag_half;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wave_m * WTM + i * 32 + frag_row;
+        fa[i] = *(const bf16x8*)(a + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wave_n * WTN + j * 32 + frag_row;
+        fb[j] = *(const bf16x8*)(b + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int col_l = lane & 31;
+  const bool out_f32 = p.flags & MVIT_OUT_F32;
+  const bool atomic = p.flags & MVIT_ATOMIC;
+  float* Cf = (float*)p.C;
+  bf16_t* Cb = (bf16_t*)p.C;
+
+  if (EPI == MVIT_EPI_SWIGLU) {
+    if constexpr (TN == 2) {
+      bf16_t* aux = (bf16_t*)p.aux;
+      const int ca = n0 + wave_n * WTN + col_l, cb = ca + 32;
+      const int cg = ((n0 + wave_n * WTN) >> 1) + col_l;
+      const float bia = p.bias ? p.bias[ca] : 0.f, bib = p.bias ? p.bias[cb] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wave_m * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_half;
+          if (row < p.M) {
+            const float a_ = acc[i][0][r] + bia, b_ = acc[i][1][r] + bib;
+            if (aux) {
+              aux[(size_t)row * p.ldaux + ca] = f2bf(a_);
+              aux[(size_t)row * p.ldaux + cb] = f2bf(b_);
+            }
+            Cb[(size_t)row * p.ldc + cg] = f2bf(a_ * sigmoidf_(a_) * b_);
+          }
+        }
+    }
+    return;
+  }
+
+  float st_s[TN], st_q[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) st_s[j] = st_q[j] = 0.f;
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wave_n * WTN + j * 32 + col_l;
+    const bool cok = col < p.N;
+    const float bias = (p.bias && cok) ? p.bias[col] : 0.f;
+    const float gam = (p.gamma && cok) ? p.gamma[col] : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave_m * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_half;
+        if (row >= p.M || !cok) continue;
+        float v = acc[i][j][r] + bias;
+        switch (EPI) {
+          case MVIT_EPI_STORE: {
+            const size_t o = (size_t)row * p.ldc + col;
+            if (atomic)
+              atomicAdd(Cf + o, v);
+            else if (out_f32)
+              Cf[o] = v;
+            else
+              Cb[o] = f2bf(v);
+          } break;
+          case MVIT_EPI_GELU: {
+            if (p.aux) ((bf16_t*)p.aux)[(size_t)row * p.ldaux + col] = f2bf(v);
+            Cb[(size_t)row * p.ldc + col] = f2bf(gelu_erf(v));
+          } break;
+          case MVIT_EPI_RESID: {
+            const size_t o = (size_t)row * p.ldc + col;
+            Cf[o] += gam * v;
+          } break;
+          case MVIT_EPI_PATCH: {
+            const int img = row / p.patch_P, pp = row - img * p.patch_P;
+            const size_t o = (size_t)(img * p.patch_ntok + p.patch_prefix + pp) * p.ldc + col;
+            Cf[o] = v + p.pos[(size_t)pp * p.N + col];
+          } break;
+          case MVIT_EPI_STATS: {
+            Cb[(size_t)row * p.ldc + col] = f2bf(v);
+            st_s[j] += v;
+            st_q[j] += v * v;
+          } break;
+          case MVIT_EPI_DSWIGLU: {
+            const bf16_t* u = (const bf16_t*)p.aux;
+            const int ca = ((col >> 5) << 6) + (col & 31);
+            const float a_ = bf2f(u[(size_t)row * p.ldaux + ca]), b_ = bf2f(u[(size_t)row * p.ldaux + ca + 32]);
+            const float sg = sigmoidf_(a_);
+            Cb[(size_t)row * p.ldc + ca] = f2bf(v * b_ * sg * (1.f + a_ * (1.f - sg)));
+            Cb[(size_t)row * p.ldc + ca + 32] = f2bf(v * a_ * sg);
+          } break;
+          case MVIT_EPI_DGELU: {
+            const float u = bf2f(((const bf16_t*)p.aux)[(size_t)row * p.ldaux + col]);
+            Cb[(size_t)row * p.ldc + col] = f2bf(v * gelu_erf_grad(u));
+          } break;
+          default: break;
+        }
+      }
+  }
+
+  if (EPI == MVIT_EPI_STATS) {
+    // per-column partials: lanes l / l^32 hold the same column; then across the WAVES_M waves via LDS
+    float* red = (float*)smem;  // [WAVES_M][BN][2]; main loop ended with a barrier, LDS is free
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s = st_s[j] + __shfl_xor(st_s[j], 32, 64);
+      const float q = st_q[j] + __shfl_xor(st_q[j], 32, 64);
+      if (lane < 32) {
+        const int c = wave_n * WTN + j * 32 + lane;
+        red[(wave_m * BN + c) * 2 + 0] = s;
+        red[(wave_m * BN + c) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      double s = 0., q = 0.;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        s += red[(w * BN + tid) * 2 + 0];
+        q += red[(w * BN + tid) * 2 + 1];
+      }
+      double* st = p.stats + (size_t)(blockIdx.x % p.nslots) * 2 * p.N;
+      atomicAdd(st + n0 + tid, s);
+      atomicAdd(st + p.N + n0 + tid, q);
+    }
+  }
+}
+
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
+int launch_one(const mvit_gemm_args& a, hipStream_t s) {
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, a.ksplit > 1 ? a.ksplit : 1);
+  const size_t lds = 2 * (BM + BN) * 128;
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>), grid, dim3(256), lds, s, a);
+  return MVIT_LAUNCH_CHECK();
+}
+
+// one translation unit per (tile, A-mode): keeps hipcc compile times parallel
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_dense(const mvit_gemm_args& a, hipStream_t s);
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_conv(const mvit_gemm_args& a, hipStream_t s);
+
+#define MVIT_GEMM_DENSE_UNIT(BM, BN, WM, WN)                                                      \
+  template <>                                                                                     \
+  int launch_dense<BM, BN, WM, WN>(const mvit_gemm_args& a, hipStream_t s) {                      \
+    switch (a.epi) {                                                                              \
+      case MVIT_EPI_STORE: return launch_one<BM, BN, WM, WN, MVIT_A_DENSE, MVIT_EPI_STORE>(a, s); \
+      case MVIT_EPI_GELU: return launch_one<BM, BN, WM, WN, MVIT_A_DENSE, MVIT_EPI_GELU>(a, s);   \
+      case MVIT_EPI_SWIGLU: return launch_one<BM, BN, WM, WN, MVIT_A_DENSE, MVIT_EPI_SWIGLU>(a, s); \
+      case MVIT_EPI_RESID: return launch_one<BM, BN, WM, WN, MVIT_A_DENSE, MVIT_EPI_RESID>(a, s); \
+      case MVIT_EPI_PATCH: return launch_one<BM, BN, WM, WN, MVIT_A_DENSE, MVIT_EPI_PATCH>(a, s); \
+      case MVIT_EPI_DSWIGLU: return launch_one<BM, BN, WM, WN, MVIT_A_DENSE, MVIT_EPI_DSWIGLU>(a, s); \
+      case MVIT_EPI_DGELU: return launch_one<BM, BN, WM, WN, MVIT_A_DENSE, MVIT_EPI_DGELU>(a, s); \
+      default: return MVIT_EINVAL;                                                                \
+    }                                                                                             \
+  }
+
+#define MVIT_GEMM_CONV_UNIT(BM, BN, WM, WN)                                                       \
+  template <>                                                                                     \
+  int launch_conv<BM, BN, WM, WN>(const mvit_gemm_args& a, hipStream_t s) {                       \
+    if (a.amode == MVIT_A_CONV3) {                                                                \
+      if (a.epi == MVIT_EPI_STATS) return launch_one<BM, BN, WM, WN, MVIT_A_CONV3, MVIT_EPI_STATS>(a, s); \
+      if (a.epi == MVIT_EPI_STORE) return launch_one<BM, BN, WM, WN, MVIT_A_CONV3, MVIT_EPI_STORE>(a, s); \
+    } else if (a.amode == MVIT_A_CONV3_T) {                                                       \
+      if (a.epi == MVIT_EPI_STORE) return launch_one<BM, BN, WM, WN, MVIT_A_CONV3_T, MVIT_EPI_STORE>(a, s); \
+    }                                                                                             \
+    return MVIT_EINVAL;                                                                           \
+  }
+
+}  // namespace mvit_gemm

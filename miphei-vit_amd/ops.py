@@ -1,0 +1,68 @@
+"""Thin torch-tensor wrappers over the C-ABI (device pointers, current HIP stream)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,  # noqa: F401
+                   EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_bf16(t, name):
+    if t.dtype != torch.bfloat16 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA bfloat16 tensor, got {t.dtype} on {t.device}")
+
+
+def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=None, b2=None, K2=0, bias=None,
+         gamma=None, aux=None, ldaux=0, pos=None, stats=None, nslots=0, epi=EPI_STORE, flags=0, ksplit=1,
+         amode=A_DENSE, conv=None, patch=None):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+ A2 @ B2^T) with a fused epilogue (mvit_gemm_bf16)."""
+    _chk_bf16(a, "A")
+    _chk_bf16(b, "B")
+    g = L.GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    g.N = N if N is not None else b.shape[0]
+    g.K = K if K is not None else b.shape[1]
+    g.ldb = ldb if ldb is not None else b.stride(0)
+    if amode == A_DENSE:
+        g.M = M if M is not None else a.shape[0]
+        g.lda = lda if lda is not None else a.stride(0)
+    else:
+        H, W, Cc, ld, OH, OW, stride = conv
+        g.conv_H, g.conv_W, g.conv_C, g.conv_ld, g.conv_OH, g.conv_OW, g.conv_stride = H, W, Cc, ld, OH, OW, stride
+        g.M = M
+        g.lda = ld
+    g.ldc = ldc if ldc is not None else c.stride(0)
+    if a2 is not None:
+        _chk_bf16(a2, "A2")
+        _chk_bf16(b2, "B2")
+        g.A2, g.B2, g.K2, g.lda2, g.ldb2 = a2.data_ptr(), b2.data_ptr(), K2 or a2.shape[1], a2.stride(0), b2.stride(0)
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        g.bias = bias.data_ptr()
+    if gamma is not None:
+        assert gamma.dtype == torch.float32
+        g.gamma = gamma.data_ptr()
+    if aux is not None:
+        g.aux, g.ldaux = aux.data_ptr(), ldaux or aux.stride(0)
+    if pos is not None:
+        assert pos.dtype == torch.float32
+        g.pos = pos.data_ptr()
+    if stats is not None:
+        assert stats.dtype == torch.float64
+        g.stats, g.nslots = stats.data_ptr(), nslots
+    if patch is not None:
+        g.patch_P, g.patch_ntok, g.patch_prefix = patch
+    g.epi, g.flags, g.ksplit, g.amode = epi, flags, ksplit, amode
+    L.check(L.lib().mvit_gemm_bf16(C.byref(g), _stream()), "mvit_gemm_bf16")
+    return c

@@ -1,0 +1,158 @@
+"""GPU parity of mvit_gemm_bf16 (MFMA GEMM + implicit-GEMM conv) against plain PyTorch fp32 math."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import miphei_vit_amd.ops as ops
+    return ops
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float(((a - b) ** 2).sum().sqrt() / b.pow(2).sum().sqrt().clamp_min(1e-30))
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device="cuda") * scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (329, 192, 96), (5264, 1536, 1536), (700, 64, 72), (1000, 48, 432),
+                                   (513, 32, 648), (260, 96, 64), (130, 288, 64)])
+def test_gemm_store(M, N, K):
+    ops = _ops()
+    a = _rand(M, K, seed=1).bfloat16()
+    b = _rand(N, K, seed=2).bfloat16()
+    bias = _rand(N, seed=3)
+    ref = a.float() @ b.float().t() + bias
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, b, c, bias=bias)
+    assert _rel(c.float(), ref) < 4e-3
+    cf = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm(a, b, cf, bias=bias, flags=ops.OUT_F32)
+    assert _rel(cf, ref) < 1e-5
+    # transpose detection: asymmetric operands, exact small integers
+    ai = torch.randint(-3, 4, (M, K), device="cuda").bfloat16()
+    bi = torch.randint(-3, 4, (N, K), device="cuda").bfloat16()
+    ops.gemm(ai, bi, cf, flags=ops.OUT_F32)
+    assert torch.equal(cf, ai.float() @ bi.float().t())
+
+
+def test_gemm_kext_and_splitk():
+    ops = _ops()
+    M, N, K, K2 = 700, 384, 256, 16
+    a, b = _rand(M, K, seed=1).bfloat16(), _rand(N, K, seed=2).bfloat16()
+    a2, b2 = _rand(M, K2, seed=3).bfloat16(), _rand(N, K2, seed=4).bfloat16()
+    ref = a.float() @ b.float().t() + a2.float() @ b2.float().t()
+    cf = torch.empty(M, N, device="cuda")
+    ops.gemm(a, b, cf, a2=a2, b2=b2, flags=ops.OUT_F32)
+    assert _rel(cf, ref) < 1e-5
+    cf.zero_()
+    ops.gemm(a, b, cf, a2=a2, b2=b2, flags=ops.OUT_F32 | ops.ATOMIC, ksplit=3)
+    assert _rel(cf, ref) < 1e-5
+
+
+def test_gemm_gelu_resid_patch():
+    ops = _ops()
+    M, N, K = 329 * 2, 256, 64
+    a, b, bias = _rand(M, K, seed=1).bfloat16(), _rand(N, K, seed=2, scale=0.2).bfloat16(), _rand(N, seed=3)
+    u = a.float() @ b.float().t() + bias
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    aux = torch.empty_like(c)
+    ops.gemm(a, b, c, bias=bias, aux=aux, epi=ops.EPI_GELU)
+    assert _rel(c.float(), F.gelu(u)) < 4e-3 and _rel(aux.float(), u) < 4e-3
+    # dgelu
+    dg = torch.empty_like(c)
+    ops.gemm(a, b, dg, aux=aux, epi=ops.EPI_DGELU)
+    uu = aux.float().requires_grad_(True)
+    (F.gelu(uu) * (a.float() @ b.float().t())).sum().backward()
+    assert _rel(dg.float(), uu.grad) < 5e-3
+    # residual + layerscale
+    x = _rand(M, N, seed=5)
+    gam = _rand(N, seed=6)
+    ref = x + gam * u
+    ops.gemm(a, b, x, bias=bias, gamma=gam, epi=ops.EPI_RESID)
+    assert _rel(x, ref) < 1e-5
+    # patch-embed epilogue
+    P, prefix, B = 81, 5, 3
+    Mp = B * P
+    ap = _rand(Mp, K, seed=7).bfloat16()
+    pos = _rand(P, N, seed=8)
+    out = torch.zeros(B * (P + prefix), N, device="cuda")
+    ops.gemm(ap, b, out, bias=bias, pos=pos, epi=ops.EPI_PATCH, patch=(P, P + prefix, prefix), flags=ops.OUT_F32)
+    ref = (ap.float() @ b.float().t() + bias).view(B, P, N) + pos
+    got = out.view(B, P + prefix, N)
+    assert _rel(got[:, prefix:], ref) < 1e-5 and float(got[:, :prefix].abs().max()) == 0.0
+
+
+def _pack_swiglu_rows(H):
+    """packed row p of fc1 -> original row: groups of 32 gate cols: [32 a | 32 b]."""
+    idx = torch.empty(2 * H, dtype=torch.long)
+    g = torch.arange(H)
+    idx[(g // 32) * 64 + g % 32] = g
+    idx[(g // 32) * 64 + 32 + g % 32] = H + g
+    return idx
+
+
+def test_gemm_swiglu_fwd_bwd():
+    ops = _ops()
+    M, D, H = 400, 96, 256
+    x = _rand(M, D, seed=1).bfloat16()
+    w = _rand(2 * H, D, seed=2, scale=0.15)
+    bias = _rand(2 * H, seed=3, scale=0.1)
+    idx = _pack_swiglu_rows(H).cuda()
+    wp, bp = w[idx].bfloat16().contiguous(), bias[idx].contiguous()
+    g = torch.empty(M, H, device="cuda", dtype=torch.bfloat16)
+    u = torch.empty(M, 2 * H, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, wp, g, bias=bp, aux=u, epi=ops.EPI_SWIGLU)
+    uref = x.float() @ w.bfloat16().float().t() + bias
+    a, b = uref[:, :H], uref[:, H:]
+    assert _rel(g.float(), F.silu(a) * b) < 5e-3
+    assert _rel(u.float()[:, idx.argsort()], uref) < 4e-3
+    # backward epilogue: dy[M,Dout] @ W2[Dout,H] -> dg, fused d(silu(a)*b)
+    Do = 64
+    dy = _rand(M, Do, seed=4).bfloat16()
+    w2t = _rand(H, Do, seed=5, scale=0.2).bfloat16()  # [N=H, K=Do]
+    du = torch.empty(M, 2 * H, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dy, w2t, du, aux=u, epi=ops.EPI_DSWIGLU)
+    dg = dy.float() @ w2t.float().t()
+    up = u.float()
+    ua = up[:, idx.argsort()]
+    aa, bb = ua[:, :H].clone().requires_grad_(True), ua[:, H:].clone().requires_grad_(True)
+    (F.silu(aa) * bb * dg).sum().backward()
+    ref = torch.cat([aa.grad, bb.grad], 1)
+    assert _rel(du.float()[:, idx.argsort()], ref) < 5e-3
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),
+                                                 (1, 24, 24, 72, 32, 1), (3, 8, 8, 1728, 256, 1)])
+def test_conv3x3_fwd_stats_and_dgrad(B, H, W, C, Cout, stride):
+    ops = _ops()
+    x = _rand(B, H, W, C, seed=1).bfloat16()  # NHWC
+    w = _rand(Cout, C, 3, 3, seed=2, scale=0.05)
+    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).bfloat16().contiguous()  # [Cout, (ky,kx,c)]
+    M = B * OH * OW
+    y = torch.empty(M, Cout, device="cuda", dtype=torch.bfloat16)
+    nslots = 8
+    stats = torch.zeros(nslots, 2, Cout, device="cuda", dtype=torch.float64)
+    ops.gemm(x, wk, y, M=M, amode=ops.A_CONV3, conv=(H, W, C, C, OH, OW, stride), epi=ops.EPI_STATS, stats=stats,
+             nslots=nslots)
+    xr = x.float().permute(0, 3, 1, 2)
+    wr = w.bfloat16().float()
+    ref = F.conv2d(xr, wr, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    assert _rel(y.float(), ref) < 4e-3
+    st = stats.sum(0)
+    assert _rel(st[0], ref.double().sum(0)) < 1e-4 and _rel(st[1], (ref.double() ** 2).sum(0)) < 1e-4
+    # adjoint (dgrad): dX[b,y,x,c] from dY
+    dy = _rand(B, OH, OW, Cout, seed=3).bfloat16()
+    wd = w.permute(1, 2, 3, 0).reshape(C, 9 * Cout).bfloat16().contiguous()  # [Cin, (ky,kx,co)]
+    dx = torch.empty(B * H * W, C, device="cuda", dtype=torch.float32)
+    ops.gemm(dy, wd, dx, M=B * H * W, amode=ops.A_CONV3_T, conv=(OH, OW, Cout, Cout, H, W, stride), flags=ops.OUT_F32)
+    xg = xr.clone().requires_grad_(True)
+    F.conv2d(xg, wr, stride=stride, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    assert _rel(dx, xg.grad.permute(0, 2, 3, 1).reshape(-1, C)) < 1e-4
