@@ -66,6 +66,43 @@ typedef struct mvit_gemm_args {
 
 MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream);
 
+/* ---------------------------------------------------------------- row-wise encoder kernels */
+/* out(bf16)[M,D] = LayerNorm(x f32 [M,D]) * w + b, biased variance, eps inside the sqrt.
+ * Replaces timm Block.norm1/norm2 and VisionTransformer.norm (nn.LayerNorm eps 1e-6) reached through
+ * src/generators/foundation_models.py:53-57 and Encoder.forward src/generators/mipheivit.py:154. */
+MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, void* out_bf16, int M, int D, float eps,
+                                mvit_stream_t stream);
+/* dx (+)= dLN/dx(dh); statistics recomputed from x.  If gamma_next/dy are given also writes
+ * dy(bf16) = gamma_next * dx_total (the LayerScale-scaled gradient of the preceding residual branch). */
+MVIT_API int mvit_layernorm_bwd(const void* dh_bf16, const float* x, const float* w, float* dx, const float* gamma_next,
+                                void* dy_bf16, int M, int D, float eps, int accumulate, mvit_stream_t stream);
+/* out(bf16)[M,R] = X(bf16)[M,K] @ W(f32)[K,R], R <= 16, W element (k,r) at W[k*wsk + r*wsr].
+ * LoRALayer.forward x @ A (src/generators/lora.py:16-18) and its adjoint dq @ B^T. */
+MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int wsr, void* out, int ldo, int M, int K,
+                            int R, mvit_stream_t stream);
+/* out(f32)[r*osr + n*osn] += sum_m X(bf16)[m,r] * Y(bf16)[m,n], R <= 16 (LoRA weight gradients dA, dB). */
+MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, int osr, int osn, int M, int N,
+                             int R, mvit_stream_t stream);
+/* NCHW f32 image -> bf16 patch matrix [B*g*g, Kp], k = c*p*p + iy*p + ix (timm PatchEmbed conv k=s=p). */
+MVIT_API int mvit_im2col_patch(const float* img, void* out_bf16, int B, int S, int p, int g, int Kp, mvit_stream_t stream);
+/* x[b,0]=cls, x[b,1..R]=reg  (timm _pos_embed with no_embed_class=True). */
+MVIT_API int mvit_prefix_tokens(float* x, const float* cls, const float* reg, int B, int ntok, int D, int R,
+                                mvit_stream_t stream);
+MVIT_API int mvit_cast_f32_bf16(const float* src, void* dst_bf16, long long n, mvit_stream_t stream);
+/* out(bf16)[M,D] = x(f32)[M,D] * gamma[D] */
+MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out_bf16, int M, int D, mvit_stream_t stream);
+
+/* ---------------------------------------------------------------- fused multi-head attention */
+/* out(bf16)[B,N,H*Dh] = softmax(q k^T * scale) v per head, reading the packed projection qkv(bf16)[B,N,3,H,Dh];
+ * lse(f32)[B,H,N] (optional) = log-sum-exp of the scaled scores, kept for the backward pass.  Dh <= 64, Dh % 8 == 0.
+ * Replaces F.scaled_dot_product_attention inside timm Attention (model built at
+ * src/generators/foundation_models.py:53-57; q,v carry LoRA deltas from src/generators/lora.py:29-33). */
+MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int Dh, float scale,
+                                mvit_stream_t stream);
+/* dqkv(bf16)[B,N,3,H,Dh] from d_out(bf16)[B,N,H*Dh]; dsum(f32)[B,H,N] is caller-provided scratch. */
+MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum,
+                                void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

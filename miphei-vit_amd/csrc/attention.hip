@@ -1,0 +1,509 @@
+// Fused multi-head self-attention (flash style) for gfx950, head_dim <= 64, non-causal, no mask.
+//
+// Reads the packed qkv projection [B, N, 3, H, Dh] (bf16) in place, as timm's Attention does after
+// qkv(x).reshape(B,N,3,H,Dh) (reached through src/generators/foundation_models.py:53-57), and writes
+// O [B, N, H*Dh].  Everything is computed in the transposed form so that the softmax axis is lane-local:
+//     S^T[key][q] = K Q^T           (A = K rows from LDS, B = Q fragment held in registers)
+//     O^T[d][q]  += V^T P^T         (A = V^T via ds_read_b64_tr_b16 on the row-major V tile, B = P from registers)
+// With v_mfma_f32_32x32x16_bf16 a lane owns one query column (lane&31) and 16 keys of each 32-key tile,
+// so the running max / sum are per-lane scalars plus one exchange with lane^32.  The register layout of
+// P (keys (e&3)+8*(e>>2)+4*half per 16-key step) is used directly as the MFMA k-slot order; the V^T
+// fragments are gathered in that same order, so P never moves between lanes.
+// Work split: 4 wavefronts x 32 queries per block, K/V tiles of 64 keys double-buffered in LDS.
+#include "common.hpp"
+#include "../../include/miphei_hip.h"
+
+namespace {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int KVB = 64;          // keys per LDS tile
+constexpr int TILE_BYTES = KVB * 128;  // 64 rows x 64 bf16
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// 4 consecutive rows x this lane's column, from a row-major [rows][64] bf16 tile (hardware transpose read):
+// a 16-lane group addresses a 4x16 block (lane i: row i>>2, cols 4*(i&3)..+3) and lane i receives column i.
+__device__ __forceinline__ v4s tr_read4(const char* tile, int row_base, int col_base16, int lane) {
+  const int i = lane & 15;
+  const int row = row_base + (i >> 2);
+  const int col = col_base16 + 4 * (i & 3);  // element column
+  const int chunk = col >> 3;
+  const char* p = tile + swz(row, chunk) + ((col & 7) << 1);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
+}
+
+__device__ __forceinline__ bf16x8 join(v4s a, v4s b) {
+  union { struct { v4s lo, hi; } s; bf16x8 v; } u;
+  u.s.lo = a;
+  u.s.hi = b;
+  return u.v;
+}
+
+struct AttnDims {
+  int B, N, H, Dh;
+  float scale;
+};
+
+// stage one 64-row tile (rows row0.. of matrix `which` of the packed qkv) into registers / LDS
+__device__ __forceinline__ void load_rows(const bf16_t* __restrict__ base, size_t row_stride, int row0, int nrows_valid,
+                                          int Dh, int tid, uint4 (&r)[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int id = tid + 256 * j, row = id >> 3, c = id & 7;
+    if (row0 + row < nrows_valid && c * 8 < Dh)
+      r[j] = *(const uint4*)(base + (size_t)(row0 + row) * row_stride + c * 8);
+    else
+      r[j] = make_uint4(0, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void store_rows(char* tile, int tid, const uint4 (&r)[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int id = tid + 256 * j, row = id >> 3, c = id & 7;
+    *(uint4*)(tile + swz(row, c)) = r[j];
+  }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  union { uint32_t u[4]; bf16x8 v; } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.u[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  return r.v;
+}
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, AttnDims dm) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
+  const int N = dm.N, Dh = dm.Dh;
+  const size_t rs = (size_t)3 * dm.H * Dh;  // row stride of packed qkv
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
+  const bf16_t* kb = qb + (size_t)dm.H * Dh;
+  const bf16_t* vb = kb + (size_t)dm.H * Dh;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q = q0 + l31;
+
+  // Q fragment (B operand: k = d, col = q)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int d = 16 * s + 8 * half;
+    uint4 t = make_uint4(0, 0, 0, 0);
+    if (q < N && d < Dh) t = *(const uint4*)(qb + (size_t)q * rs + d);
+    qf[s] = *(bf16x8*)&t;
+  }
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = dm.scale * LOG2E;
+
+  uint4 rk[2], rv[2];
+  const int ntiles = (N + KVB - 1) / KVB;
+  load_rows(kb, rs, 0, N, Dh, tid, rk);
+  load_rows(vb, rs, 0, N, Dh, tid, rv);
+  store_rows(smem, tid, rk);
+  store_rows(smem + TILE_BYTES, tid, rv);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      load_rows(kb, rs, (t + 1) * KVB, N, Dh, tid, rk);
+      load_rows(vb, rs, (t + 1) * KVB, N, Dh, tid, rv);
+    }
+    const char* Ks = smem + cur * 2 * TILE_BYTES;
+    const char* Vs = Ks + TILE_BYTES;
+    const int kv0 = t * KVB;
+
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
+      }
+    }
+    // online softmax (log2 domain)
+    float mloc = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float v = key < N ? st[kt][r] * sc : -1e30f;
+        st[kt][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = exp2f(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(st[kt][r] - m_new);
+        st[kt][r] = p;
+        lsum += p;
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int kt = s2 >> 1, h2 = s2 & 1;
+      float pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = st[kt][8 * h2 + e];
+      const bf16x8 pb = pack8(pv);
+      const int kbase = 32 * kt + 16 * h2 + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
+        const bf16x8 a = join(tr_read4(Vs, kbase, cb, lane), tr_read4(Vs, kbase + 8, cb, lane));
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES, tid, rk);
+      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, tid, rv);
+    }
+    __syncthreads();
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q < N) {
+    bf16_t* orow = out + ((size_t)b * N + q) * ((size_t)dm.H * Dh) + (size_t)h * Dh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * half;
+        if (d < Dh) {
+          uint2 w;
+          w.x = pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv);
+          w.y = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+          *(uint2*)(orow + d) = w;
+        }
+      }
+    if (lse && half == 0) lse[(size_t)bh * N + q] = (m_run + log2f(l_tot)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------ backward, preparation: D[b,h,q] = sum_d dO*O
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO,
+                                                            float* __restrict__ Dv, AttnDims dm) {
+  // one thread per (b, q, h)
+  const long long total = (long long)dm.B * dm.N * dm.H;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int h = (int)(i % dm.H);
+  const long long bq = i / dm.H;
+  const int qq = (int)(bq % dm.N), b = (int)(bq / dm.N);
+  const bf16_t* po = o + (size_t)i * dm.Dh;
+  const bf16_t* pd = dO + (size_t)i * dm.Dh;
+  float s = 0.f;
+  for (int d = 0; d < dm.Dh; d += 8) {
+    const uint4 a = *(const uint4*)(po + d), c = *(const uint4*)(pd + d);
+    const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, uc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s += __uint_as_float(ua[j] << 16) * __uint_as_float(uc[j] << 16);
+      s += __uint_as_float(ua[j] & 0xffff0000u) * __uint_as_float(uc[j] & 0xffff0000u);
+    }
+  }
+  Dv[((size_t)b * dm.H + h) * dm.N + qq] = s;
+}
+
+// ------------------------------------------------------------------ backward, dQ (query-stationary, S^T form)
+//   S^T = K Q^T, P = exp(S*scale - L), dP^T = V dO^T, dS^T = P*(dP^T - D)*scale, dQ^T += K^T dS^T
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                          bf16_t* __restrict__ dqkv, AttnDims dm) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
+  const int N = dm.N, Dh = dm.Dh;
+  const size_t rs = (size_t)3 * dm.H * Dh, ors = (size_t)dm.H * Dh;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
+  const bf16_t* kb = qb + (size_t)dm.H * Dh;
+  const bf16_t* vb = kb + (size_t)dm.H * Dh;
+  const bf16_t* dob = dO + (size_t)b * N * ors + (size_t)h * Dh;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int d = 16 * s + 8 * half;
+    uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+    if (q < N && d < Dh) {
+      t = *(const uint4*)(qb + (size_t)q * rs + d);
+      u = *(const uint4*)(dob + (size_t)q * ors + d);
+    }
+    qf[s] = *(bf16x8*)&t;
+    dof[s] = *(bf16x8*)&u;
+  }
+  const float Lq = q < N ? lse[(size_t)bh * N + q] * LOG2E : 0.f;
+  const float Dq = q < N ? Dv[(size_t)bh * N + q] : 0.f;
+  const float sc = dm.scale * LOG2E;
+
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
+
+  uint4 rk[2], rv[2];
+  const int ntiles = (N + KVB - 1) / KVB;
+  load_rows(kb, rs, 0, N, Dh, tid, rk);
+  load_rows(vb, rs, 0, N, Dh, tid, rv);
+  store_rows(smem, tid, rk);
+  store_rows(smem + TILE_BYTES, tid, rv);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      load_rows(kb, rs, (t + 1) * KVB, N, Dh, tid, rk);
+      load_rows(vb, rs, (t + 1) * KVB, N, Dh, tid, rv);
+    }
+    const char* Ks = smem + cur * 2 * TILE_BYTES;
+    const char* Vs = Ks + TILE_BYTES;
+    const int kv0 = t * KVB;
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f, dp[kt][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
+        const bf16x8 v = *(const bf16x8*)(Vs + swz(32 * kt + l31, 2 * s + half));
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, dof[s], dp[kt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float p = key < N ? exp2f(st[kt][r] * sc - Lq) : 0.f;
+        st[kt][r] = p * (dp[kt][r] - Dq) * dm.scale;  // dS^T
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int kt = s2 >> 1, h2 = s2 & 1;
+      float pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = st[kt][8 * h2 + e];
+      const bf16x8 dsb = pack8(pv);
+      const int kbase = 32 * kt + 16 * h2 + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
+        const bf16x8 a = join(tr_read4(Ks, kbase, cb, lane), tr_read4(Ks, kbase + 8, cb, lane));
+        dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb, dqacc[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES, tid, rk);
+      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, tid, rv);
+    }
+    __syncthreads();
+  }
+  if (q < N) {
+    bf16_t* orow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * Dh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * half;
+        if (d < Dh) {
+          uint2 w;
+          w.x = pack2bf(dqacc[dt][4 * g], dqacc[dt][4 * g + 1]);
+          w.y = pack2bf(dqacc[dt][4 * g + 2], dqacc[dt][4 * g + 3]);
+          *(uint2*)(orow + d) = w;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------ backward, dK / dV (key-stationary, S form)
+//   S = Q K^T, P = exp(S*scale - L_q), dP = dO V^T, dS = P*(dP - D_q)*scale, dV^T += dO^T P, dK^T += Q^T dS
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                           bf16_t* __restrict__ dqkv, AttnDims dm) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 2 * 2 * KVB * 4];  // [buf][Q|dO] + [buf][L|D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
+  const int N = dm.N, Dh = dm.Dh;
+  const size_t rs = (size_t)3 * dm.H * Dh, ors = (size_t)dm.H * Dh;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
+  const bf16_t* kb = qb + (size_t)dm.H * Dh;
+  const bf16_t* vb = kb + (size_t)dm.H * Dh;
+  const bf16_t* dob = dO + (size_t)b * N * ors + (size_t)h * Dh;
+  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  float* LD = (float*)(smem + 4 * TILE_BYTES);  // [buf][2][64]
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int d = 16 * s + 8 * half;
+    uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+    if (key < N && d < Dh) {
+      t = *(const uint4*)(kb + (size_t)key * rs + d);
+      u = *(const uint4*)(vb + (size_t)key * rs + d);
+    }
+    kf[s] = *(bf16x8*)&t;
+    vf[s] = *(bf16x8*)&u;
+  }
+  const float sc = dm.scale * LOG2E;
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dkacc[i][r] = 0.f, dvacc[i][r] = 0.f;
+
+  uint4 rq[2], rd[2];
+  float rl = 0.f;
+  const int ntiles = (N + KVB - 1) / KVB;
+  auto load_ld = [&](int row0) {
+    // threads 0..63: L, 64..127: D
+    if (tid < 128) {
+      const int i = tid & 63, qq = row0 + i;
+      rl = qq < N ? (tid < 64 ? lse[(size_t)bh * N + qq] * LOG2E : Dv[(size_t)bh * N + qq]) : 0.f;
+    }
+  };
+  auto store_ld = [&](int buf) {
+    if (tid < 128) LD[buf * 128 + tid] = rl;
+  };
+  load_rows(qb, rs, 0, N, Dh, tid, rq);
+  load_rows(dob, ors, 0, N, Dh, tid, rd);
+  load_ld(0);
+  store_rows(smem, tid, rq);
+  store_rows(smem + TILE_BYTES, tid, rd);
+  store_ld(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      load_rows(qb, rs, (t + 1) * KVB, N, Dh, tid, rq);
+      load_rows(dob, ors, (t + 1) * KVB, N, Dh, tid, rd);
+      load_ld((t + 1) * KVB);
+    }
+    const char* Qs = smem + cur * 2 * TILE_BYTES;
+    const char* Ds = Qs + TILE_BYTES;
+    const float* Ls = LD + cur * 128;
+    const int qt0 = t * KVB;
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[qt][r] = 0.f, dp[qt][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a = *(const bf16x8*)(Qs + swz(32 * qt + l31, 2 * s + half));
+        st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], st[qt], 0, 0, 0);
+        const bf16x8 g = *(const bf16x8*)(Ds + swz(32 * qt + l31, 2 * s + half));
+        dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, vf[s], dp[qt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float p = (qt0 + ql < N) ? exp2f(st[qt][r] * sc - Ls[ql]) : 0.f;
+        st[qt][r] = p;                                          // P
+        dp[qt][r] = p * (dp[qt][r] - Ls[64 + ql]) * dm.scale;  // dS
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int qt = s2 >> 1, h2 = s2 & 1;
+      float pv[8], dv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = st[qt][8 * h2 + e], dv[e] = dp[qt][8 * h2 + e];
+      const bf16x8 pb = pack8(pv), dsb = pack8(dv);
+      const int qbase = 32 * qt + 16 * h2 + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
+        const bf16x8 a = join(tr_read4(Ds, qbase, cb, lane), tr_read4(Ds, qbase + 8, cb, lane));
+        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, dvacc[dt], 0, 0, 0);
+        const bf16x8 a2 = join(tr_read4(Qs, qbase, cb, lane), tr_read4(Qs, qbase + 8, cb, lane));
+        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb, dkacc[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES, tid, rq);
+      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, tid, rd);
+      store_ld(cur ^ 1);
+    }
+    __syncthreads();
+  }
+  if (key < N) {
+    bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)(dm.H + h) * Dh;
+    bf16_t* vrow = krow + (size_t)dm.H * Dh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * half;
+        if (d < Dh) {
+          uint2 w;
+          w.x = pack2bf(dkacc[dt][4 * g], dkacc[dt][4 * g + 1]);
+          w.y = pack2bf(dkacc[dt][4 * g + 2], dkacc[dt][4 * g + 3]);
+          *(uint2*)(krow + d) = w;
+          w.x = pack2bf(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
+          w.y = pack2bf(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
+          *(uint2*)(vrow + d) = w;
+        }
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int Dh, float scale,
+                                mvit_stream_t stream) {
+  if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
+  AttnDims dm{B, N, H, Dh, scale};
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qkv, (bf16_t*)out, lse, dm);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum,
+                                void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream) {
+  if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
+  AttnDims dm{B, N, H, Dh, scale};
+  hipStream_t s = (hipStream_t)stream;
+  const long long tot = (long long)B * N * H;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
+                     (const bf16_t*)d_out, dsum, dm);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 127) / 128, B * H), dim3(256), 0, s, (const bf16_t*)qkv,
+                     (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 127) / 128, B * H), dim3(256), 0, s, (const bf16_t*)qkv,
+                     (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
+  return MVIT_LAUNCH_CHECK();
+}
+
+}  // extern "C"

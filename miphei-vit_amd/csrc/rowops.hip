@@ -1,0 +1,316 @@
+// Row-wise / skinny kernels of the ViT encoder: LayerNorm fwd/bwd (wave per row, wave-level
+// reductions over 64 lanes), rank-r LoRA products, patch gather, prefix tokens, casts.
+// All HBM-bound: 16-byte loads per lane, rows kept in registers between the reduction passes.
+#include "common.hpp"
+#include "../../include/miphei_hip.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+
+// ------------------------------------------------------------------ LayerNorm forward
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, bf16_t* __restrict__ out, int M, int D,
+                                                     float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nv = D >> 2;
+  const float4* xr = (const float4*)(x + (size_t)row * D);
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      v[i] = xr[idx];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + bb * bb) + (c * c + d * d);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  uint2* o = (uint2*)(out + (size_t)row * D);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      const float4 ww = ((const float4*)w)[idx], bv = ((const float4*)b)[idx];
+      uint2 r;
+      r.x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
+      r.y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
+      o[idx] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward (input grad only)
+// dx (+)= rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * w.  Statistics are recomputed from x.
+// Optionally emits dy = bf16(gamma_next * dx_total): the LayerScale-scaled gradient the next dgrad GEMM consumes.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dh, const float* __restrict__ x,
+                                                     const float* __restrict__ w, float* __restrict__ dx,
+                                                     const float* __restrict__ gamma_next, bf16_t* __restrict__ dy,
+                                                     int M, int D, float eps, int accumulate) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nv = D >> 2;
+  const float4* xr = (const float4*)(x + (size_t)row * D);
+  const uint2* gr = (const uint2*)(dh + (size_t)row * D);
+  float4 v[LN_MAXV], g[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      v[i] = xr[idx];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      const uint2 t = gr[idx];
+      const float4 ww = ((const float4*)w)[idx];
+      g[i].x = __uint_as_float(t.x << 16) * ww.x;
+      g[i].y = __uint_as_float(t.x & 0xffff0000u) * ww.y;
+      g[i].z = __uint_as_float(t.y << 16) * ww.z;
+      g[i].w = __uint_as_float(t.y & 0xffff0000u) * ww.w;
+    }
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      v[i].x *= rs; v[i].y *= rs; v[i].z *= rs; v[i].w *= rs;  // xhat
+      c1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      c2 += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+    }
+  }
+  c1 = wave_sum(c1) / D;
+  c2 = wave_sum(c2) / D;
+  float4* dxr = (float4*)(dx + (size_t)row * D);
+  uint2* dyr = dy ? (uint2*)(dy + (size_t)row * D) : nullptr;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      float4 r;
+      r.x = rs * (g[i].x - c1 - v[i].x * c2);
+      r.y = rs * (g[i].y - c1 - v[i].y * c2);
+      r.z = rs * (g[i].z - c1 - v[i].z * c2);
+      r.w = rs * (g[i].w - c1 - v[i].w * c2);
+      if (accumulate) {
+        const float4 o = dxr[idx];
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+      }
+      dxr[idx] = r;
+      if (dyr) {
+        const float4 gm = ((const float4*)gamma_next)[idx];
+        uint2 p;
+        p.x = pack2bf(r.x * gm.x, r.y * gm.y);
+        p.y = pack2bf(r.z * gm.z, r.w * gm.w);
+        dyr[idx] = p;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ out[M,R] = X[M,K] @ W[K,R], R <= 16
+__global__ __launch_bounds__(256) void skinny_xw_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                        int wsk, int wsr, bf16_t* __restrict__ out, int ldo, int M, int K,
+                                                        int R) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bf16_t* xr = X + (size_t)row * ldx;
+  for (int k0 = lane * 8; k0 < K; k0 += 512) {
+    const uint4 t = *(const uint4*)(xr + k0);
+    const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xv = (j & 1) ? __uint_as_float(u[j >> 1] & 0xffff0000u) : __uint_as_float(u[j >> 1] << 16);
+      const float* wr = W + (size_t)(k0 + j) * wsk;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (r < R) acc[r] += xv * wr[(size_t)r * wsr];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane < R) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (lane == r) v = acc[r];
+    out[(size_t)row * ldo + lane] = f2bf(v);
+  }
+}
+
+// ------------------------------------------------------------------ out[r,n] += sum_m X[m,r] * Y[m,n], R <= 16
+constexpr int XTY_ROWS = 128;
+__global__ __launch_bounds__(256) void skinny_xty_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y,
+                                                         int ldy, float* __restrict__ out, int osr, int osn, int M, int N,
+                                                         int R) {
+  __shared__ float xs[XTY_ROWS][16];
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int mbeg = blockIdx.y * XTY_ROWS, mend = min(M, mbeg + XTY_ROWS);
+  for (int i = threadIdx.x; i < XTY_ROWS * 16; i += 256) {
+    const int m = mbeg + (i >> 4), r = i & 15;
+    xs[i >> 4][r] = (m < M && r < R) ? bf2f(X[(size_t)m * ldx + r]) : 0.f;
+  }
+  __syncthreads();
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int m = mbeg; m < mend; ++m) {
+    const float y = bf2f(Y[(size_t)m * ldy + n]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += xs[m - mbeg][r] * y;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (r < R) atomicAdd(out + (size_t)r * osr + (size_t)n * osn, acc[r]);
+}
+
+// ------------------------------------------------------------------ patch gather: NCHW f32 image -> [B*g*g, Kp] bf16
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B,
+                                                           int S, int p, int g, int Kp) {
+  const long long total = (long long)B * g * g * Kp;
+  const int pp = p * p, K = 3 * pp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const long long row = i / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / pp, rem = k - c * pp, iy = rem / p, ix = rem - iy * p;
+      const int gx = (int)(row % g), gy = (int)((row / g) % g), b = (int)(row / ((long long)g * g));
+      v = img[(((size_t)b * 3 + c) * S + gy * p + iy) * S + gx * p + ix];
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void prefix_tokens_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                            const float* __restrict__ reg, int B, int ntok, int D, int R) {
+  const int total = B * (1 + R) * D;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int d = i % D, t = (i / D) % (1 + R), b = i / (D * (1 + R));
+    x[((size_t)b * ntok + t) * D + d] = t == 0 ? cls[d] : reg[(size_t)(t - 1) * D + d];
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 v = *(const float4*)(src + i);
+      uint2 r;
+      r.x = pack2bf(v.x, v.y);
+      r.y = pack2bf(v.z, v.w);
+      *(uint2*)(dst + i) = r;
+    } else {
+      for (long long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_cols_cast_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              bf16_t* __restrict__ out, int M, int D) {
+  const long long nv = (long long)M * D / 4;
+  const int dv = D >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const float4 v = ((const float4*)x)[i];
+    const float4 g = ((const float4*)gamma)[i % dv];
+    uint2 r;
+    r.x = pack2bf(v.x * g.x, v.y * g.y);
+    r.y = pack2bf(v.z * g.z, v.w * g.w);
+    ((uint2*)out)[i] = r;
+  }
+}
+
+inline int nblocks(long long work, int per_block, int cap = 8192) {
+  long long b = (work + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, void* out, int M, int D, float eps,
+                                mvit_stream_t stream) {
+  if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)out, M, D, eps);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, float* dx, const float* gamma_next,
+                                void* dy, int M, int D, float eps, int accumulate, mvit_stream_t stream) {
+  if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
+  if ((dy != nullptr) != (gamma_next != nullptr)) return MVIT_EINVAL;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, x, w, dx,
+                     gamma_next, (bf16_t*)dy, M, D, eps, accumulate);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int wsr, void* out, int ldo, int M, int K,
+                            int R, mvit_stream_t stream) {
+  if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7)) return MVIT_EINVAL;
+  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, W, wsk,
+                     wsr, (bf16_t*)out, ldo, M, K, R);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, int osr, int osn, int M, int N,
+                             int R, mvit_stream_t stream) {
+  if (M <= 0 || N <= 0 || R <= 0 || R > 16) return MVIT_EINVAL;
+  hipLaunchKernelGGL(skinny_xty_kernel, dim3((N + 255) / 256, (M + XTY_ROWS - 1) / XTY_ROWS), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, out, osr, osn, M, N, R);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_im2col_patch(const float* img, void* out, int B, int S, int p, int g, int Kp, mvit_stream_t stream) {
+  if (B <= 0 || g <= 0 || g * p > S || Kp < 3 * p * p || (Kp & 7)) return MVIT_EINVAL;
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3(nblocks((long long)B * g * g * Kp, 256)), dim3(256), 0, (hipStream_t)stream,
+                     img, (bf16_t*)out, B, S, p, g, Kp);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_prefix_tokens(float* x, const float* cls, const float* reg, int B, int ntok, int D, int R,
+                                mvit_stream_t stream) {
+  if (B <= 0 || D <= 0 || R < 0 || ntok < 1 + R) return MVIT_EINVAL;
+  hipLaunchKernelGGL(prefix_tokens_kernel, dim3(nblocks((long long)B * (1 + R) * D, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, cls, reg, B, ntok, D, R);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_cast_f32_bf16(const float* src, void* dst, long long n, mvit_stream_t stream) {
+  if (n <= 0) return MVIT_EINVAL;
+  hipLaunchKernelGGL(cast_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out, int M, int D, mvit_stream_t stream) {
+  if (M <= 0 || D <= 0 || (D & 3)) return MVIT_EINVAL;
+  hipLaunchKernelGGL(scale_cols_cast_kernel, dim3(nblocks((long long)M * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     gamma, (bf16_t*)out, M, D);
+  return MVIT_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -66,3 +66,63 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     g.epi, g.flags, g.ksplit, g.amode = epi, flags, ksplit, amode
     L.check(L.lib().mvit_gemm_bf16(C.byref(g), _stream()), "mvit_gemm_bf16")
     return c
+
+
+def _call(name, *args):
+    L.check(getattr(L.lib(), name)(*args, _stream()), name)
+
+
+def layernorm_fwd(x, w, b, out, eps=1e-6):
+    M, D = x.shape
+    _call("mvit_layernorm_fwd", _p(x), _p(w), _p(b), _p(out), M, D, eps)
+    return out
+
+
+def layernorm_bwd(dh, x, w, dx, gamma_next=None, dy=None, eps=1e-6, accumulate=True):
+    M, D = x.shape
+    _call("mvit_layernorm_bwd", _p(dh), _p(x), _p(w), _p(dx), _p(gamma_next), _p(dy), M, D, eps, int(accumulate))
+
+
+def skinny_xw(X, W, out, *, ldx=None, wsk=None, wsr=None, ldo=None, M=None, K=None, R=None):
+    M = M or X.shape[0]
+    _call("mvit_skinny_xw", _p(X), ldx or X.stride(0), _p(W), wsk if wsk is not None else W.stride(0),
+          wsr if wsr is not None else W.stride(1), _p(out), ldo or out.stride(0), M, K or W.shape[0], R or W.shape[1])
+    return out
+
+
+def skinny_xty(X, Y, out, *, ldx=None, ldy=None, osr=None, osn=None, M=None, N=None, R=None):
+    _call("mvit_skinny_xty", _p(X), ldx or X.stride(0), _p(Y), ldy or Y.stride(0), _p(out),
+          osr if osr is not None else out.stride(0), osn if osn is not None else out.stride(1), M or X.shape[0],
+          N or Y.shape[1], R or X.shape[1])
+    return out
+
+
+def im2col_patch(img, out, patch, grid):
+    B, _, S, _ = img.shape
+    _call("mvit_im2col_patch", _p(img), _p(out), B, S, patch, grid, out.shape[1])
+    return out
+
+
+def prefix_tokens(x, cls, reg, B, ntok, D, R):
+    _call("mvit_prefix_tokens", _p(x), _p(cls), _p(reg), B, ntok, D, R)
+
+
+def cast_bf16(src, dst):
+    _call("mvit_cast_f32_bf16", _p(src), _p(dst), src.numel())
+    return dst
+
+
+def scale_cols_cast(x, gamma, out):
+    M, D = x.shape
+    _call("mvit_scale_cols_cast", _p(x), _p(gamma), _p(out), M, D)
+    return out
+
+
+def attention_fwd(qkv, out, lse, B, N, H, Dh, scale):
+    _call("mvit_attention_fwd", _p(qkv), _p(out), _p(lse), B, N, H, Dh, scale)
+    return out
+
+
+def attention_bwd(qkv, out, d_out, lse, dsum, dqkv, B, N, H, Dh, scale):
+    _call("mvit_attention_bwd", _p(qkv), _p(out), _p(d_out), _p(lse), _p(dsum), _p(dqkv), B, N, H, Dh, scale)
+    return dqkv
