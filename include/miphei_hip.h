@@ -31,13 +31,13 @@ enum mvit_epilogue {
   MVIT_EPI_STORE = 0,    /* C = acc (+bias)                                                  */
   MVIT_EPI_GELU = 1,     /* u = acc+bias; aux<-u (optional); C = gelu_erf(u)                 */
   MVIT_EPI_SWIGLU = 2,   /* packed fc1: C[m, g] = silu(a)*b, aux<-[a|b] (optional)           */
-  MVIT_EPI_RESID = 3,    /* C(f32, in place) += gamma[n]*(acc+bias[n])   (LayerScale + res)  */
+  MVIT_EPI_RESID = 3,    /* C(f32) = (aux f32 | C) + gamma[n]*(acc+bias[n]) (LayerScale+res) */
   MVIT_EPI_PATCH = 4,    /* patch-embed: row remap past prefix tokens, +bias +pos_embed      */
   MVIT_EPI_STATS = 5,    /* C = bf16(acc) and per-column sum / sum-of-squares (BatchNorm)    */
   MVIT_EPI_DSWIGLU = 6,  /* C[m, packed a|b] = d(silu(a)*b) * acc, aux = saved [a|b]         */
   MVIT_EPI_DGELU = 7     /* C = acc * gelu'(aux)                                             */
 };
-enum mvit_gemm_flags { MVIT_OUT_F32 = 1, MVIT_ATOMIC = 2 };
+enum mvit_gemm_flags { MVIT_OUT_F32 = 1, MVIT_ATOMIC = 2 /* f32 atomicAdd (split-K) */, MVIT_ACCUM_BF16 = 4 /* C(bf16) += */ };
 enum mvit_amode { MVIT_A_DENSE = 0, MVIT_A_CONV3 = 1, MVIT_A_CONV3_T = 2 };
 
 /*
@@ -102,6 +102,78 @@ MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, i
 /* dqkv(bf16)[B,N,3,H,Dh] from d_out(bf16)[B,N,H*Dh]; dsum(f32)[B,H,N] is caller-provided scratch. */
 MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum,
                                 void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream);
+
+/* ---------------------------------------------------------------- decoder data movement (NHWC bf16) */
+/* dst[b,oy,ox,c] = sum_{ty,tx} ty_w[oy,ty]*tx_w[ox,tx] * f(src[b, ty_idx[oy,ty], tx_idx[ox,tx], c]),
+ * f = identity or relu(v*scale[c]+shift[c]) (BatchNorm+ReLU of the producer fused into the gather).
+ * With host-built tap tables this is F.interpolate(bilinear x2, align_corners=False) of Fusion_Block
+ * (src/generators/mipheivit.py:89), the bicubic regrid of Encoder.forward (mipheivit.py:147-151,161-162)
+ * and the adjoint (backward) of either.  C, ld_src, ld_dst multiples of 8; *_bstride in elements. */
+MVIT_API int mvit_resample2d(const void* src, void* dst, const int* ty_idx, const float* ty_w, const int* tx_idx,
+                             const float* tx_w, const float* scale, const float* shift, int B, int h, int w, int H, int W,
+                             int C, int ld_src, int ld_dst, long long src_bstride, long long dst_bstride, int T,
+                             mvit_stream_t stream);
+/* NCHW f32 image -> channels [0,C) of an NHWC bf16 buffer with pixel stride ld_dst; nzero trailing channels cleared
+ * (D0 skip of Detail_Capture.forward, mipheivit.py:208-211, and the ConvStream input). */
+MVIT_API int mvit_image_to_nhwc(const float* img, void* dst, int B, int S, int C, int ld_dst, int nzero,
+                                mvit_stream_t stream);
+/* nn.BatchNorm2d (eps 1e-5, momentum 0.1; mipheivit.py:33) from the conv epilogue's [nslots][2][C] f64 sums:
+ * scale = gamma*rstd, shift = beta - mean*scale; training!=0 uses batch statistics and updates the running ones. */
+MVIT_API int mvit_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
+                              int nslots, double count, float eps, float momentum, int training, mvit_stream_t stream);
+MVIT_API int mvit_bn_relu_apply(const void* x, const float* scale, const float* shift, void* out, long long M, int C,
+                                int ld_x, int ld_out, mvit_stream_t stream);
+/* backward of relu(BN(x)): reduce (sum g, sum g*xhat into [nslots][2][C] f64) then apply (dx, dgamma+=, dbeta+=). */
+MVIT_API int mvit_bn_relu_bwd_reduce(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
+                                     const float* mean, const float* rstd, double* stats, long long M, int C, int nslots,
+                                     mvit_stream_t stream);
+MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
+                                    const float* mean, const float* rstd, const float* gamma, const double* stats,
+                                    float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
+                                    mvit_stream_t stream);
+/* dst[c][r] = src[r][c] (bf16) and the transposed im2col out[(ky,kx,c)][m] of a 3x3/pad-1 window: the K-contiguous
+ * operands of the weight-gradient GEMMs dW^T[k,co] = sum_m Xcol^T[k,m] dY^T[co,m]. */
+MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int ld_src, long long ld_dst,
+                                 mvit_stream_t stream);
+MVIT_API int mvit_im2col_t(const void* x, void* out, int B, int H, int W, int C, int ld, int OH, int OW, int stride,
+                           mvit_stream_t stream);
+
+/* ---------------------------------------------------------------- fused output heads (<=16 SegmentationHeads) */
+/* x = fusion output [M,32] bf16.  Stacked parameters: W1[NH,16,32], b1/gamma/beta/running_*[NH*16], W2[NH,16],
+ * b2[NH], W3[NH,9,32] ((ky,kx) major), b3[NH].   src/generators/unet.py:407-438, mipheivit.py:198-218. */
+MVIT_API int mvit_heads_moments(const void* x, double* mom /*[nslots][32+32*32]*/, long long M, int nslots,
+                                mvit_stream_t stream);
+MVIT_API int mvit_heads_bn_from_moments(const double* mom, const float* W1, const float* b1, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float* scale,
+                                        float* shift, float* mean_out, float* rstd_out, double* mom_sum, int NH, int nslots,
+                                        double count, float eps, float momentum, int training, mvit_stream_t stream);
+MVIT_API int mvit_heads_gate_fwd(const void* x, const float* W1, const float* b1, const float* scale, const float* shift,
+                                 const float* W2, const float* b2, void* G /*bf16 [M,16]*/, long long M, int NH,
+                                 mvit_stream_t stream);
+MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, const float* b3, float* out /*NCHW f32*/,
+                                 int B, int H, int W, int NH, mvit_stream_t stream);
+MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x, const void* G, const float* W3,
+                                 void* ET /*bf16 [NH*9, M]*/, float* dG /*[M,16]*/, float* dXc /*[M,32]*/, float* db3, int B,
+                                 int H, int W, int NH, mvit_stream_t stream);
+MVIT_API int mvit_heads_gate_bwd(const void* x, const void* G, const float* dG, const float* dXc, const float* W1,
+                                 const float* b1, const float* scale, const float* shift, const float* mean,
+                                 const float* rstd, const float* gamma, const float* W2, const double* mom_sum,
+                                 double* red /*[nslots][NH*16][36], zeroed*/, float* coef /*[NH*16][2]*/, float* dW1,
+                                 float* dgamma, float* dbeta, float* dW2, float* db2, void* dF /*bf16 [M,32]*/, long long M,
+                                 int NH, int nslots, double count, mvit_stream_t stream);
+
+/* ---------------------------------------------------------------- loss / optimiser */
+/* WeightedMSELoss (src/loss.py:47-57): loss_acc += sum_c w_c sum (p-t)^2 (caller multiplies by lambda/(C*B*HW));
+ * dY = 2*lambda/(C*B*HW) * w_c * (p-t).  pred/target/dY are NCHW f32. */
+MVIT_API int mvit_wmse_fwd_bwd(const float* pred, const float* target, const float* w, double* loss_acc, float* dY, int B,
+                               int C, long long HW, float lambda_factor, mvit_stream_t stream);
+MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t stream);
+/* clip_grad_norm_(max_norm) + torch.optim.Adam step on flat f32 buffers (src/models.py:136-138,359-371);
+ * sqnorm = device scalar holding sum g^2 (no host sync), bias_c{1,2} = 1-beta^t. */
+MVIT_API int mvit_adam_clip_step(float* p, const float* g, float* m, float* v, const double* sqnorm, long long n, float lr,
+                                 float beta1, float beta2, float eps, float bias_c1, float bias_c2, float max_norm,
+                                 mvit_stream_t stream);
 
 #ifdef __cplusplus
 }

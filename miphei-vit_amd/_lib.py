@@ -12,10 +12,10 @@ LIB_PATH = os.path.join(_HERE, "libmiphei_hip.so")
 
 # enum mvit_epilogue
 EPI_STORE, EPI_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_STATS, EPI_DSWIGLU, EPI_DGELU = range(8)
-OUT_F32, ATOMIC = 1, 2
+OUT_F32, ATOMIC, ACCUM_BF16 = 1, 2, 4
 A_DENSE, A_CONV3, A_CONV3_T = 0, 1, 2
 
-vp, ci, cf, cd = C.c_void_p, C.c_int, C.c_float, C.c_double
+vp, ci, cf, cd, ll = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong
 
 
 class GemmArgs(C.Structure):
@@ -45,6 +45,23 @@ SIGNATURES = {
     "mvit_scale_cols_cast": [vp, vp, vp, ci, ci, vp],
     "mvit_attention_fwd": [vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_attention_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
+    "mvit_resample2d": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ll, ll, ci, vp],
+    "mvit_image_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
+    "mvit_bn_finalize": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cf, cf, ci, vp],
+    "mvit_bn_relu_apply": [vp, vp, vp, vp, ll, ci, ci, ci, vp],
+    "mvit_bn_relu_bwd_reduce": [vp, ci, vp, vp, vp, vp, vp, vp, ll, ci, ci, vp],
+    "mvit_bn_relu_bwd_apply": [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, cd, vp],
+    "mvit_transpose_bf16": [vp, vp, ci, ci, ci, ll, vp],
+    "mvit_im2col_t": [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "mvit_heads_moments": [vp, vp, ll, ci, vp],
+    "mvit_heads_bn_from_moments": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cf, cf, ci, vp],
+    "mvit_heads_gate_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp],
+    "mvit_heads_conv_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mvit_heads_conv_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mvit_heads_gate_bwd": [vp] * 21 + [ll, ci, ci, cd, vp],
+    "mvit_wmse_fwd_bwd": [vp, vp, vp, vp, vp, ci, ci, ll, cf, vp],
+    "mvit_sqnorm": [vp, vp, ll, vp],
+    "mvit_adam_clip_step": [vp, vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, cf, vp],
 }
 
 _lib = None

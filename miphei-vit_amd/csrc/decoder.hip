@@ -1,0 +1,359 @@
+// Decoder-side data movement kernels (all HBM-bound, NHWC bf16, 16-byte accesses per lane):
+//   tap-table resampler  - bilinear x2 upsample (Fusion_Block, src/generators/mipheivit.py:89), bicubic
+//                          token-grid regrid (Encoder.forward, mipheivit.py:147-151,161-162) and the
+//                          adjoints of both, with BatchNorm+ReLU optionally applied to the gathered source
+//                          and the result written straight into a channel slice of the concat buffer
+//   BatchNorm statistics finalisation / apply / backward (nn.BatchNorm2d in Basic_Conv3x3, mipheivit.py:33)
+//   transposes feeding the weight-gradient GEMMs.
+#include "common.hpp"
+#include "../../include/miphei_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& t, float (&f)[8]) {
+  const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = __uint_as_float(u[j] << 16);
+    f[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8f(const float (&f)[8]) {
+  uint4 r;
+  r.x = pack2bf(f[0], f[1]);
+  r.y = pack2bf(f[2], f[3]);
+  r.z = pack2bf(f[4], f[5]);
+  r.w = pack2bf(f[6], f[7]);
+  return r;
+}
+
+// ------------------------------------------------------------------ separable tap-table resampler
+struct ResampleArgs {
+  const bf16_t* src;
+  bf16_t* dst;
+  const int* ty_idx;
+  const float* ty_w;
+  const int* tx_idx;
+  const float* tx_w;
+  const float* scale;  // optional: relu(v*scale[c] + shift[c]) applied to every gathered source value
+  const float* shift;
+  int B, h, w, H, W, C, ld_src, ld_dst, T;
+  long long src_bstride, dst_bstride;
+};
+
+__global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs a) {
+  const int cv = a.C >> 3;
+  const long long total = (long long)a.B * a.H * a.W * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % cv);
+    long long r = i / cv;
+    const int ox = (int)(r % a.W);
+    r /= a.W;
+    const int oy = (int)(r % a.H), b = (int)(r / a.H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    float sc[8], sh[8];
+    if (a.scale) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sc[j] = a.scale[c8 * 8 + j], sh[j] = a.shift[c8 * 8 + j];
+    }
+    const bf16_t* sb = a.src + (size_t)b * a.src_bstride + c8 * 8;
+    for (int ty = 0; ty < a.T; ++ty) {
+      const float wy = a.ty_w[oy * a.T + ty];
+      if (wy == 0.f) continue;
+      const int iy = a.ty_idx[oy * a.T + ty];
+      for (int tx = 0; tx < a.T; ++tx) {
+        const float wx = a.tx_w[ox * a.T + tx];
+        if (wx == 0.f) continue;
+        const int ix = a.tx_idx[ox * a.T + tx];
+        const uint4 t = *(const uint4*)(sb + ((size_t)iy * a.w + ix) * a.ld_src);
+        float f[8];
+        unpack8(t, f);
+        const float wgt = wy * wx;
+        if (a.scale) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += wgt * fmaxf(f[j] * sc[j] + sh[j], 0.f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += wgt * f[j];
+        }
+      }
+    }
+    *(uint4*)(a.dst + (size_t)b * a.dst_bstride + ((size_t)oy * a.W + ox) * a.ld_dst + c8 * 8) = pack8f(acc);
+  }
+}
+
+// ------------------------------------------------------------------ NCHW f32 image -> NHWC bf16 channel slice
+__global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ img, bf16_t* __restrict__ dst, int B,
+                                                            int S, int C, int ld_dst, int nzero) {
+  const long long total = (long long)B * S * S;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i % ((long long)S * S);
+    const int b = (int)(i / ((long long)S * S));
+    bf16_t* o = dst + (size_t)i * ld_dst;
+    for (int c = 0; c < C; ++c) o[c] = f2bf(img[((size_t)b * C + c) * S * S + pix]);
+    for (int c = 0; c < nzero; ++c) o[C + c] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm: statistics -> scale / shift
+// stats: [nslots][2][C] doubles (sum, sum of squares) accumulated by the conv epilogue.
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                   float* __restrict__ rstd_o, int C, int nslots, double count, float eps, float momentum,
+                                   int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (training) {
+    double s = 0., q = 0.;
+    for (int k = 0; k < nslots; ++k) {
+      s += stats[(size_t)k * 2 * C + c];
+      q += stats[(size_t)k * 2 * C + C + c];
+    }
+    mean = s / count;
+    var = q / count - mean * mean;
+    if (var < 0.) var = 0.;
+    const double unb = count > 1. ? var * count / (count - 1.) : var;
+    rmean[c] = (float)((1. - momentum) * rmean[c] + momentum * mean);
+    rvar[c] = (float)((1. - momentum) * rvar[c] + momentum * unb);
+  } else {
+    mean = rmean[c];
+    var = rvar[c];
+  }
+  const double rstd = 1. / sqrt(var + (double)eps);
+  const double sc = gamma[c] * rstd;
+  scale[c] = (float)sc;
+  shift[c] = (float)(beta[c] - mean * sc);
+  if (mean_o) mean_o[c] = (float)mean;
+  if (rstd_o) rstd_o[c] = (float)rstd;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, bf16_t* __restrict__ out,
+                                                            long long M, int C, int ld_x, int ld_out) {
+  const int cv = C >> 3;
+  const long long total = M * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % cv);
+    const long long m = i / cv;
+    float f[8];
+    unpack8(*(const uint4*)(x + (size_t)m * ld_x + c8 * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * scale[c8 * 8 + j] + shift[c8 * 8 + j], 0.f);
+    *(uint4*)(out + (size_t)m * ld_out + c8 * 8) = pack8f(f);
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm+ReLU backward
+// reduce: per channel  s1 = sum g, s2 = sum g*xhat,  g = dy * [x*scale+shift > 0]
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* __restrict__ dy, int ld_dy,
+                                                                 const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 double* __restrict__ stats, long long M, int C, int nslots) {
+  __shared__ float red[2 * 256];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int cv = C >> 3;
+  const int c8 = threadIdx.x % cv, rl = threadIdx.x / cv, rpb = 256 / cv;
+  float s1[8], s2[8], sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = s2[j] = 0.f;
+    sc[j] = scale[c8 * 8 + j], sh[j] = shift[c8 * 8 + j], mu[j] = mean[c8 * 8 + j], rs[j] = rstd[c8 * 8 + j];
+  }
+  if (rl < rpb) {
+    for (long long m = (long long)blockIdx.x * rpb + rl; m < M; m += (long long)gridDim.x * rpb) {
+      float g[8], xv[8];
+      unpack8(*(const uint4*)(dy + (size_t)m * ld_dy + c8 * 8), g);
+      unpack8(*(const uint4*)(x + (size_t)m * C + c8 * 8), xv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gg = (xv[j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;
+        s1[j] += gg;
+        s2[j] += gg * (xv[j] - mu[j]) * rs[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&red[c8 * 8 + j], s1[j]);
+      atomicAdd(&red[C + c8 * 8 + j], s2[j]);
+    }
+  }
+  __syncthreads();
+  double* st = stats + (size_t)(blockIdx.x % nslots) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(st + i, (double)red[i]);
+}
+
+// apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); block 0 also emits dgamma += s2, dbeta += s1
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __restrict__ dy, int ld_dy,
+                                                                const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const double* __restrict__ stats, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, bf16_t* __restrict__ dx,
+                                                                long long M, int C, int nslots, double count) {
+  __shared__ float s1s[256], s2s[256];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0., b = 0.;
+    for (int k = 0; k < nslots; ++k) {
+      a += stats[(size_t)k * 2 * C + c];
+      b += stats[(size_t)k * 2 * C + C + c];
+    }
+    s1s[c] = (float)(a / count);
+    s2s[c] = (float)(b / count);
+    if (blockIdx.x == 0) {
+      dgamma[c] += (float)b;
+      dbeta[c] += (float)a;
+    }
+  }
+  __syncthreads();
+  const int cv = C >> 3;
+  const long long total = M * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % cv);
+    const long long m = i / cv;
+    float g[8], xv[8];
+    unpack8(*(const uint4*)(dy + (size_t)m * ld_dy + c8 * 8), g);
+    unpack8(*(const uint4*)(x + (size_t)m * C + c8 * 8), xv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      const float gg = (xv[j] * scale[c] + shift[c] > 0.f) ? g[j] : 0.f;
+      const float xh = (xv[j] - mean[c]) * rstd[c];
+      g[j] = gamma[c] * rstd[c] * (gg - s1s[c] - xh * s2s[c]);
+    }
+    *(uint4*)(dx + (size_t)m * C + c8 * 8) = pack8f(g);
+  }
+}
+
+// ------------------------------------------------------------------ dst[c][r] = src[r][c]   (64x64 LDS tiles)
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R,
+                                                        int Cc, int ld_src, long long ld_dst) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < Cc) ? src[(size_t)(r0 + r) * ld_src + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < R && c0 + c < Cc) dst[(size_t)(c0 + c) * ld_dst + r0 + r] = tile[r][c];
+  }
+}
+
+// ------------------------------------------------------------------ transposed im2col: out[(tap,c)][m] for 3x3 pad 1
+__global__ __launch_bounds__(256) void im2col_t_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H,
+                                                       int W, int C, int ld, int OH, int OW, int stride, long long M) {
+  __shared__ bf16_t tile[64][66];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int ky = tap / 3, kx = tap - ky * 3;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const long long m = m0 + r;
+    bf16_t v = 0;
+    if (m < M && c0 + c < C) {
+      const int ox = (int)(m % OW);
+      const long long t = m / OW;
+      const int oy = (int)(t % OH), b = (int)(t / OH);
+      const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * H + iy) * W + ix) * ld + c0 + c];
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (m0 + r < M && c0 + c < C) out[((size_t)tap * C + c0 + c) * M + m0 + r] = tile[r][c];
+  }
+}
+
+inline int nblk(long long work, int per, int cap = 16384) {
+  long long b = (work + per - 1) / per;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+MVIT_API int mvit_resample2d(const void* src, void* dst, const int* ty_idx, const float* ty_w, const int* tx_idx,
+                             const float* tx_w, const float* scale, const float* shift, int B, int h, int w, int H, int W,
+                             int C, int ld_src, int ld_dst, long long src_bstride, long long dst_bstride, int T,
+                             mvit_stream_t stream) {
+  if (B <= 0 || C <= 0 || (C & 7) || (ld_src & 7) || (ld_dst & 7) || T <= 0 || T > 16) return MVIT_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return MVIT_EINVAL;
+  ResampleArgs a{(const bf16_t*)src, (bf16_t*)dst, ty_idx, ty_w, tx_idx, tx_w, scale, shift, B, h, w, H, W, C,
+                 ld_src, ld_dst, T, src_bstride, dst_bstride};
+  hipLaunchKernelGGL(resample_kernel, dim3(nblk((long long)B * H * W * (C >> 3), 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_image_to_nhwc(const float* img, void* dst, int B, int S, int C, int ld_dst, int nzero,
+                                mvit_stream_t stream) {
+  if (B <= 0 || S <= 0 || C <= 0 || C + nzero > ld_dst) return MVIT_EINVAL;
+  hipLaunchKernelGGL(image_to_nhwc_kernel, dim3(nblk((long long)B * S * S, 256)), dim3(256), 0, (hipStream_t)stream, img,
+                     (bf16_t*)dst, B, S, C, ld_dst, nzero);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
+                              int nslots, double count, float eps, float momentum, int training, mvit_stream_t stream) {
+  if (C <= 0 || (training && (!stats || nslots <= 0 || count <= 0))) return MVIT_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, gamma, beta,
+                     running_mean, running_var, scale, shift, mean_out, rstd_out, C, nslots, count, eps, momentum, training);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_bn_relu_apply(const void* x, const float* scale, const float* shift, void* out, long long M, int C,
+                                int ld_x, int ld_out, mvit_stream_t stream) {
+  if (M <= 0 || C <= 0 || (C & 7) || (ld_x & 7) || (ld_out & 7)) return MVIT_EINVAL;
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(nblk(M * (C >> 3), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, scale, shift, (bf16_t*)out, M, C, ld_x, ld_out);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_bn_relu_bwd_reduce(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
+                                     const float* mean, const float* rstd, double* stats, long long M, int C, int nslots,
+                                     mvit_stream_t stream) {
+  if (M <= 0 || C <= 0 || (C & 7) || C > 256 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
+  const int rpb = 256 / (C >> 3);
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk(M, rpb * 16, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, stats, M, C, nslots);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
+                                    const float* mean, const float* rstd, const float* gamma, const double* stats,
+                                    float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
+                                    mvit_stream_t stream) {
+  if (M <= 0 || C <= 0 || (C & 7) || C > 256 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(nblk(M * (C >> 3), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta,
+                     (bf16_t*)dx, M, C, nslots, count);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int ld_src, long long ld_dst,
+                                 mvit_stream_t stream) {
+  if (R <= 0 || Cc <= 0) return MVIT_EINVAL;
+  hipLaunchKernelGGL(transpose_kernel, dim3((R + 63) / 64, (Cc + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, R, Cc, ld_src, ld_dst);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_im2col_t(const void* x, void* out, int B, int H, int W, int C, int ld, int OH, int OW, int stride,
+                           mvit_stream_t stream) {
+  if (B <= 0 || C <= 0 || stride <= 0) return MVIT_EINVAL;
+  const long long M = (long long)B * OH * OW;
+  hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((M + 63) / 64), (C + 63) / 64, 9), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)out, B, H, W, C, ld, OH, OW, stride, M);
+  return MVIT_LAUNCH_CHECK();
+}
+
+}  // extern "C"

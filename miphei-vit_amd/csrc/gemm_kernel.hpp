@@ -255,6 +255,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
               atomicAdd(Cf + o, v);
             else if (out_f32)
               Cf[o] = v;
+            else if (p.flags & MVIT_ACCUM_BF16)
+              Cb[o] = f2bf(bf2f(Cb[o]) + v);
             else
               Cb[o] = f2bf(v);
           } break;
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
           } break;
           case MVIT_EPI_RESID: {
             const size_t o = (size_t)row * p.ldc + col;
-            Cf[o] += gam * v;
+            const float res = p.aux ? ((const float*)p.aux)[(size_t)row * p.ldaux + col] : Cf[o];
+            Cf[o] = res + gam * v;
           } break;
           case MVIT_EPI_PATCH: {
             const int img = row / p.patch_P, pp = row - img * p.patch_P;

@@ -1,0 +1,753 @@
+"""HIP execution engine of the MIPHEI-ViT generator (forward, backward, fused training step).
+
+Sequences the C-ABI kernels of ``libmiphei_hip.so`` for the module graph the reference builds in
+``/root/reference/src/generators/mipheivit.py`` (``ViTMatte.forward`` :106-110, ``Encoder.forward`` :153-163,
+``Detail_Capture.forward`` :207-220), the timm ViT it wraps (``foundation_models.py:53-57``), LoRA
+(``lora.py:8-33``) and the hot part of ``ModelModule.training_step`` (``/root/reference/src/models.py:87-143``).
+
+Data layout in HBM
+  * tokens: rows of a [B*N, D] matrix; residual stream f32, every GEMM operand bf16 (f32 accumulate on MFMA)
+  * frozen weights: bf16 [out, in] (K-contiguous "B^T" operands) plus their transposes for the dgrad GEMMs,
+    SwiGLU fc1 rows interleaved in groups of 32 (a|b) so the gate is applied in the fc1 epilogue
+  * decoder activations: NHWC bf16; every Fusion_Block input is one "concat" buffer [B,H,W,Cskip+Cup] written in
+    place by its producers (no torch.cat), BatchNorm+ReLU of a producer is applied by the consumer-side gather
+  * trainable parameters (LoRA + decoder) live in ONE flat f32 buffer (module parameters are views into it) with a
+    matching flat gradient buffer: one clip+Adam launch and at most two all-reduce buckets per step.
+There is no fallback path: without the HIP library / a ROCm device this raises.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace as NS
+
+import torch
+
+from . import ops
+from .ops import (A_CONV3, A_CONV3_T, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,
+                  EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
+from .resample import taps
+
+NSLOTS = 32
+BN_EPS, BN_MOM = 1e-5, 0.1
+CONV_CH = (3, 48, 96, 192)
+FUS_OUT = (256, 128, 64, 32)
+HEAD_C, HEAD_HID = 32, 16
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def swiglu_pack_index(hidden):
+    """Row order of the packed fc1 weight: per 32 gate columns, 32 'a' rows then their 32 'b' rows."""
+    H = hidden // 2
+    g = torch.arange(H)
+    idx = torch.empty(hidden, dtype=torch.long)
+    idx[(g // 32) * 64 + g % 32] = g
+    idx[(g // 32) * 64 + 32 + g % 32] = H + g
+    return idx
+
+
+class HipEngine:
+    def __init__(self, model):
+        self.model = model
+        self.invalidate()
+
+    # ------------------------------------------------------------------ state management
+    def invalidate(self):
+        self._frozen = None
+        self._flat = None
+        self._ws = {}
+        self._pack_key = None
+        self._saved = None
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def _require_gpu(self):
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("the MIPHEI-ViT HIP engine needs the model on a ROCm device (model.cuda()); "
+                               "there is no CPU fallback")
+        return dev
+
+    def _config(self):
+        vit = self.model.encoder.vit
+        g = vit.patch_embed.grid_size
+        S = vit.patch_embed.img_size
+        if g[0] != g[1] or S[0] != S[1]:
+            raise NotImplementedError("square tiles only")
+        qkv0 = vit.blocks[0].attn.qkv
+        lora = hasattr(qkv0, "lora_q")
+        c = NS(D=vit.embed_dim, L=len(vit.blocks), H=vit.num_heads, patch=vit.patch_embed.patch_size[0], grid=g[0], S=S[0],
+               nreg=vit.reg_tokens, prefix=vit.num_prefix_tokens, swiglu=vit.mlp_type == "swiglu", hidden=vit.hidden,
+               eps=vit.ln_eps, lora=lora, NH=self.model.decoder.num_heads)
+        c.Dh = c.D // c.H
+        c.ntok = c.grid * c.grid + c.prefix
+        c.Hg = c.hidden // 2 if c.swiglu else c.hidden
+        c.Kp = _pad8(3 * c.patch * c.patch)
+        if lora:
+            c.rank = qkv0.lora_q.rank
+            c.alpha = float(qkv0.lora_q.alpha)
+            if 2 * c.rank > 16 or (2 * c.rank) % 8:
+                raise NotImplementedError("LoRA rank must be 4 or 8")
+        if c.D % 8 or c.Dh % 8 or c.Dh > 64:
+            raise NotImplementedError("embed_dim % 8 == 0 and head_dim in {8..64} required")
+        if c.swiglu and c.hidden % 128:
+            raise NotImplementedError("SwiGLU hidden size must be a multiple of 128")
+        if c.NH > 16:
+            raise NotImplementedError("at most 16 output heads")
+        return c
+
+    # ------------------------------------------------------------------ flat trainable parameters
+    def _heads(self):
+        dec = self.model.decoder
+        return [getattr(dec, f"segmentation_head_{i}") for i in range(dec.num_heads)]
+
+    def _ensure_flat(self):
+        if self._flat is not None:
+            return self._flat
+        dev = self._require_gpu()
+        c = self._config()
+        vit, dec = self.model.encoder.vit, self.model.decoder
+        groups = []  # (name, [params]) in flat order
+        if c.lora:
+            for blk in vit.blocks:
+                q = blk.attn.qkv
+                groups += [q.lora_q.A, q.lora_q.B, q.lora_v.A, q.lora_v.B]
+        n_lora = sum(p.numel() for p in groups)
+        convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
+        for cv in convs:
+            groups += [cv.conv.weight, cv.bn.weight, cv.bn.bias]
+        heads = self._heads()
+        stacked = [("W1", lambda h: h[0].psi[0].weight), ("b1", lambda h: h[0].psi[0].bias),
+                   ("bnw", lambda h: h[0].psi[1].weight), ("bnb", lambda h: h[0].psi[1].bias),
+                   ("W2", lambda h: h[0].psi[3].weight), ("b2", lambda h: h[0].psi[3].bias),
+                   ("W3", lambda h: h[1].weight), ("b3", lambda h: h[1].bias)]
+        head_off = {}
+        off = sum(p.numel() for p in groups)
+        for name, get in stacked:
+            head_off[name] = off
+            for h in heads:
+                groups.append(get(h))
+                off += get(h).numel()
+        for p in groups:
+            if p.dtype != torch.float32:
+                raise RuntimeError("training needs fp32 master parameters (do not call .half()/.bfloat16() on a model "
+                                   "you train)")
+        n = sum(p.numel() for p in groups)
+        flat = torch.empty(n, device=dev, dtype=torch.float32)
+        gflat = torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        gview = {}
+        for p in groups:
+            k = p.numel()
+            flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + k].view(p.shape)
+            gview[id(p)] = gflat[o:o + k].view(p.shape)
+            p.grad = gview[id(p)] if p.requires_grad else None
+            o += k
+        f = NS(flat=flat, gflat=gflat, n=n, n_lora=n_lora, params=groups, m=None, v=None, step=0, gview=gview)
+        NH = c.NH
+
+        def hv(buf, name, shape):
+            k = int(torch.tensor(shape).prod())
+            return buf[head_off[name]:head_off[name] + k].view(shape)
+
+        for buf, pre in ((flat, ""), (gflat, "d")):
+            setattr(f, pre + "W1", hv(buf, "W1", (NH, HEAD_HID, HEAD_C)))
+            setattr(f, pre + "b1", hv(buf, "b1", (NH * HEAD_HID,)))
+            setattr(f, pre + "bnw", hv(buf, "bnw", (NH * HEAD_HID,)))
+            setattr(f, pre + "bnb", hv(buf, "bnb", (NH * HEAD_HID,)))
+            setattr(f, pre + "W2", hv(buf, "W2", (NH, HEAD_HID)))
+            setattr(f, pre + "b2", hv(buf, "b2", (NH,)))
+            setattr(f, pre + "W3", hv(buf, "W3", (NH, HEAD_C, 9)))
+            setattr(f, pre + "b3", hv(buf, "b3", (NH,)))
+        if c.lora:
+            per = 4 * c.rank * c.D
+            for buf, pre in ((flat, ""), (gflat, "d")):
+                reg = buf[:n_lora].view(c.L, 4, c.rank * c.D)
+                setattr(f, pre + "Aq", reg[:, 0].view(c.L, c.D, c.rank))
+                setattr(f, pre + "Bq", reg[:, 1].view(c.L, c.rank, c.D))
+                setattr(f, pre + "Av", reg[:, 2].view(c.L, c.D, c.rank))
+                setattr(f, pre + "Bv", reg[:, 3].view(c.L, c.rank, c.D))
+            assert per * c.L == n_lora
+        # running statistics: heads stacked, all num_batches_tracked share one tensor
+        bns = [cv.bn for cv in convs] + [h[0].psi[1] for h in heads]
+        nbt = torch.stack([b.num_batches_tracked.to(dev) for b in bns]).contiguous()
+        for i, b in enumerate(bns):
+            b.num_batches_tracked = nbt[i]
+        f.nbt = nbt
+        rm = torch.cat([h[0].psi[1].running_mean.detach().float() for h in heads]).to(dev).contiguous()
+        rv = torch.cat([h[0].psi[1].running_var.detach().float() for h in heads]).to(dev).contiguous()
+        for i, h in enumerate(heads):
+            h[0].psi[1].running_mean = rm[i * HEAD_HID:(i + 1) * HEAD_HID]
+            h[0].psi[1].running_var = rv[i * HEAD_HID:(i + 1) * HEAD_HID]
+        f.head_rm, f.head_rv = rm, rv
+        f.convs = convs
+        self._flat = f
+        return f
+
+    # ------------------------------------------------------------------ frozen encoder weights -> bf16 operands
+    def _ensure_frozen(self):
+        if self._frozen is not None:
+            return self._frozen
+        dev = self._require_gpu()
+        c = self._config()
+        vit = self.model.encoder.vit
+        bf = torch.bfloat16
+
+        def w16(t):
+            return t.detach().to(device=dev, dtype=bf).contiguous()
+
+        def f32(t):
+            return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        fz = NS(blocks=[])
+        wp = vit.patch_embed.proj.weight.detach().reshape(c.D, -1)
+        wpp = torch.zeros(c.D, c.Kp, device=dev, dtype=bf)
+        wpp[:, :wp.shape[1]] = wp.to(dev)
+        fz.wpatch, fz.bpatch = wpp, f32(vit.patch_embed.proj.bias)
+        fz.pos = f32(vit.pos_embed.reshape(-1, c.D))
+        fz.cls = f32(vit.cls_token.reshape(-1))
+        fz.reg = f32(vit.reg_token.reshape(-1, c.D)) if c.nreg else fz.cls
+        fz.nw, fz.nb = f32(vit.norm.weight), f32(vit.norm.bias)
+        idx = swiglu_pack_index(c.hidden).to(dev) if c.swiglu else None
+        for blk in vit.blocks:
+            lin = blk.attn.qkv.qkv if c.lora else blk.attn.qkv
+            b = NS()
+            b.n1w, b.n1b, b.n2w, b.n2b = f32(blk.norm1.weight), f32(blk.norm1.bias), f32(blk.norm2.weight), f32(blk.norm2.bias)
+            b.wqkv, b.bqkv = w16(lin.weight), f32(lin.bias)
+            b.wproj, b.bproj = w16(blk.attn.proj.weight), f32(blk.attn.proj.bias)
+            w1, b1 = blk.mlp.fc1.weight.detach().to(dev), blk.mlp.fc1.bias.detach().to(dev)
+            if c.swiglu:
+                w1, b1 = w1[idx], b1[idx]
+            b.wfc1, b.bfc1 = w16(w1), f32(b1)
+            b.wfc2, b.bfc2 = w16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+            b.ls1, b.ls2 = f32(blk.ls1.gamma), f32(blk.ls2.gamma)
+            b.t = None
+            fz.blocks.append(b)
+        self._frozen = fz
+        return fz
+
+    def _ensure_frozen_bwd(self):
+        fz = self._ensure_frozen()
+        for b in fz.blocks:
+            if b.t is None:
+                b.t = NS(wqkv=b.wqkv.t().contiguous(), wproj=b.wproj.t().contiguous(), wfc1=b.wfc1.t().contiguous(),
+                         wfc2=b.wfc2.t().contiguous())
+        return fz
+
+    # ------------------------------------------------------------------ per-step packs of the trainable weights
+    def _pack_trainable(self, need_bwd):
+        c = self._config()
+        dev = self._require_gpu()
+        dec = self.model.decoder
+        vit = self.model.encoder.vit
+        params = list(dec.parameters()) + ([p for blk in vit.blocks for p in blk.attn.qkv.lora_q.parameters()] +
+                                           [p for blk in vit.blocks for p in blk.attn.qkv.lora_v.parameters()] if c.lora else [])
+        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:4]), need_bwd)
+        if self._pack_key == key:
+            return self._pack
+        bf = torch.bfloat16
+        pk = NS()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
+        fl = self._flat
+        if c.lora:
+            if fl is not None:
+                Aq, Av, Bq, Bv = fl.Aq, fl.Av, fl.Bq, fl.Bv
+            else:
+                Aq = torch.stack([f32(b.attn.qkv.lora_q.A) for b in vit.blocks])
+                Av = torch.stack([f32(b.attn.qkv.lora_v.A) for b in vit.blocks])
+                Bq = torch.stack([f32(b.attn.qkv.lora_q.B) for b in vit.blocks])
+                Bv = torch.stack([f32(b.attn.qkv.lora_v.B) for b in vit.blocks])
+            r, D = c.rank, c.D
+            pk.Acat = torch.cat([Aq, Av], dim=2).contiguous()                      # [L, D, 2r] f32
+            B2 = torch.zeros(c.L, 3 * D, 2 * r, device=dev, dtype=bf)
+            B2[:, :D, :r] = (c.alpha * Bq).transpose(1, 2)
+            B2[:, 2 * D:, r:] = (c.alpha * Bv).transpose(1, 2)
+            pk.B2 = B2                                                              # [L, 3D, 2r] bf16
+            if need_bwd:
+                pk.Acat16 = pk.Acat.to(bf)                                          # B2 operand of the dh1 GEMM
+                pk.Bq, pk.Bv = (c.alpha * Bq).contiguous(), (c.alpha * Bv).contiguous()
+        convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
+        pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
+        for i, cv in enumerate(convs):
+            w = f32(cv.conv.weight)                                                 # [Cout, Cin, 3, 3]
+            cout, cin = w.shape[0], w.shape[1]
+            perm = None
+            if i == len(convs) - 1:                                                 # fus3: internal order [up(64) | img(3)]
+                perm = torch.cat([torch.arange(3, cin), torch.arange(0, 3)]).to(dev)
+                w = w[:, perm]
+            cp = _pad8(cin)
+            wp = torch.zeros(cout, cp, 3, 3, device=dev)
+            wp[:, :cin] = w
+            pk.wk.append(wp.permute(0, 2, 3, 1).reshape(cout, 9 * cp).to(bf).contiguous())
+            if need_bwd:
+                pk.wd.append(wp.permute(1, 2, 3, 0).reshape(cp, 9 * cout).to(bf).contiguous())
+            pk.cin.append(cin)
+            pk.cin_pad.append(cp)
+            pk.perm.append(perm)
+        heads = self._heads()
+        st = lambda get, shape: torch.stack([f32(get(h)).reshape(-1) for h in heads]).reshape(shape).contiguous()
+        NH = c.NH
+        if fl is not None:
+            pk.W1, pk.b1, pk.bnw, pk.bnb, pk.W2, pk.b2, pk.b3 = fl.W1, fl.b1, fl.bnw, fl.bnb, fl.W2, fl.b2, fl.b3
+            pk.W3k = fl.W3.transpose(1, 2).contiguous()
+        else:
+            pk.W1 = st(lambda h: h[0].psi[0].weight, (NH, HEAD_HID, HEAD_C))
+            pk.b1 = st(lambda h: h[0].psi[0].bias, (NH * HEAD_HID,))
+            pk.bnw = st(lambda h: h[0].psi[1].weight, (NH * HEAD_HID,))
+            pk.bnb = st(lambda h: h[0].psi[1].bias, (NH * HEAD_HID,))
+            pk.W2 = st(lambda h: h[0].psi[3].weight, (NH, HEAD_HID))
+            pk.b2 = st(lambda h: h[0].psi[3].bias, (NH,))
+            pk.W3k = st(lambda h: h[1].weight, (NH, HEAD_C, 9)).transpose(1, 2).contiguous()   # [NH, 9, 32]
+            pk.b3 = st(lambda h: h[1].bias, (NH,))
+        pk.bn = [NS(w=f32(cv.bn.weight).contiguous(), b=f32(cv.bn.bias).contiguous()) for cv in convs]
+        self._pack_key, self._pack = key, pk
+        return pk
+
+    # ------------------------------------------------------------------ workspaces
+    def _workspace(self, B, train):
+        c = self._config()
+        key = (B, c.S, train)
+        if key in self._ws:
+            return self._ws[key]
+        dev = self._require_gpu()
+        bf = torch.bfloat16
+        e = lambda *s, dt=bf: torch.empty(*s, device=dev, dtype=dt)
+        z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
+        M, D, S = B * c.ntok, c.D, c.S
+        w = NS(B=B, M=M)
+        w.patches = e(B * c.grid * c.grid, c.Kp)
+        nl = c.L if train else 1
+        w.x_in = [e(M, D, dt=torch.float32) for _ in range(nl + 1)] if train else [e(M, D, dt=torch.float32)]
+        w.x_mid = [e(M, D, dt=torch.float32) for _ in range(nl)]
+        w.h1 = [e(M, D) for _ in range(nl)]
+        w.h2 = e(M, D)
+        w.t = [e(M, 16) for _ in range(nl)] if c.lora else None
+        w.qkv = [e(M, 3 * D) for _ in range(nl)]
+        w.o = [e(M, D) for _ in range(nl)]
+        w.lse = [e(B, c.H, c.ntok, dt=torch.float32) for _ in range(nl)]
+        w.u = [e(M, c.hidden) for _ in range(nl)] if train else None
+        w.g = e(M, c.Hg)
+        w.tok = e(M, D)
+        G = S // 16
+        s1, s2, s3 = S // 2, S // 4, S // 8
+        w.res = (S, s1, s2, s3, G)
+        w.feat = e(B, G, G, D)
+        w.img8 = e(B, S, S, 8)
+        w.cat = [e(B, s3, s3, CONV_CH[3] + D), e(B, s2, s2, CONV_CH[2] + FUS_OUT[0]), e(B, s1, s1, CONV_CH[1] + FUS_OUT[1]),
+                 z(B, S, S, _pad8(CONV_CH[0] + FUS_OUT[2]))]
+        w.pre_c = [e(B * s1 * s1, 48), e(B * s2 * s2, 96), e(B * s3 * s3, 192)]
+        w.pre_f = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64), e(B * S * S, 32)]
+        w.F3 = e(B * S * S, HEAD_C)
+        w.G = e(B * S * S, 16)
+        w.out = e(B, c.NH, S, S, dt=torch.float32)
+        chans = [48, 96, 192, 256, 128, 64, 32]
+        nch = c.NH * HEAD_HID
+        w.bnp = [NS(scale=e(ch, dt=torch.float32), shift=e(ch, dt=torch.float32), mean=e(ch, dt=torch.float32),
+                    rstd=e(ch, dt=torch.float32)) for ch in chans]
+        w.hbn = NS(scale=e(nch, dt=torch.float32), shift=e(nch, dt=torch.float32), mean=e(nch, dt=torch.float32),
+                   rstd=e(nch, dt=torch.float32))
+        # f64 arena: forward stats | heads moments | mom_sum | (backward) stats | heads red | loss | sqnorm
+        sizes = [NSLOTS * 2 * ch for ch in chans] + [NSLOTS * (32 + 1024), 32 + 1024]
+        w.arena_f = z(sum(sizes), dt=torch.float64)
+        offs = [0]
+        for s_ in sizes:
+            offs.append(offs[-1] + s_)
+        w.stats_f = [w.arena_f[offs[i]:offs[i + 1]] for i in range(7)]
+        w.mom = w.arena_f[offs[7]:offs[8]]
+        w.mom_sum = w.arena_f[offs[8]:offs[9]]
+        if train:
+            sizes_b = [NSLOTS * 2 * ch for ch in chans] + [NSLOTS * nch * 36, 2]
+            w.arena_b = z(sum(sizes_b), dt=torch.float64)
+            ob = [0]
+            for s_ in sizes_b:
+                ob.append(ob[-1] + s_)
+            w.stats_b = [w.arena_b[ob[i]:ob[i + 1]] for i in range(7)]
+            w.hred = w.arena_b[ob[7]:ob[8]]
+            w.loss_acc = w.arena_b[ob[8]:ob[8] + 1]
+            w.sqn = w.arena_b[ob[8] + 1:ob[8] + 2]
+            # gradients / scratch
+            w.dY = e(B, c.NH, S, S, dt=torch.float32)
+            w.ET = e(c.NH * 9, B * S * S)
+            w.dG = e(B * S * S, 16, dt=torch.float32)
+            w.dXc = e(B * S * S, HEAD_C, dt=torch.float32)
+            w.dF3 = e(B * S * S, HEAD_C)
+            w.coef = e(nch, 2, dt=torch.float32)
+            w.dpre_c = [e(B * s1 * s1, 48), e(B * s2 * s2, 96), e(B * s3 * s3, 192)]
+            w.dpre_f = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64), e(B * S * S, 32)]
+            w.dcat = [e(B * s3 * s3, CONV_CH[3] + D), e(B * s2 * s2, CONV_CH[2] + FUS_OUT[0]),
+                      e(B * s1 * s1, CONV_CH[1] + FUS_OUT[1]), e(B * S * S, FUS_OUT[2])]
+            w.dFpost = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64)]
+            w.dfeat = e(B, G, G, D)
+            pix = [B * s1 * s1, B * s2 * s2, B * s3 * s3, B * s3 * s3, B * s2 * s2, B * s1 * s1, B * S * S]
+            cinp = [8, 48, 96, _pad8(192 + D), _pad8(96 + 256), _pad8(48 + 128), _pad8(3 + 64)]
+            w.xcolT = e(max(9 * cp * m_ for cp, m_ in zip(cinp, pix)))
+            w.dyT = e(max(max(ch * m_ for ch, m_ in zip(chans, pix)), HEAD_C * B * S * S))
+            wsz = [9 * cp * ch for cp, ch in zip(cinp, chans)] + [c.NH * 9 * HEAD_C]
+            w.wscr = z(sum(wsz), dt=torch.float32)
+            ow = [0]
+            for s_ in wsz:
+                ow.append(ow[-1] + s_)
+            w.dWt = [w.wscr[ow[i]:ow[i + 1]].view(9 * cinp[i], chans[i]) for i in range(7)]
+            w.dW3 = w.wscr[ow[7]:ow[8]].view(c.NH * 9, HEAD_C)
+            w.dtok = z(M, D)
+            w.dx = e(M, D, dt=torch.float32)
+            w.dy = e(M, D)
+            w.du = e(M, c.hidden)
+            w.dh = e(M, D)
+            w.do = e(M, D)
+            w.dqkv = e(M, 3 * D)
+            w.dsum = e(B, c.H, c.ntok, dt=torch.float32)
+            w.dt = e(M, 16) if c.lora else None
+        self._ws[key] = w
+        return w
+
+    # ------------------------------------------------------------------ forward
+    def _encoder_fwd(self, w, x, train, pk):
+        c, fz = self._config(), self._ensure_frozen()
+        B, M, D = w.B, w.M, c.D
+        P = c.grid * c.grid
+        ops.im2col_patch(x, w.patches, c.patch, c.grid)
+        X = w.x_in[0]
+        ops.prefix_tokens(X, fz.cls, fz.reg, B, c.ntok, D, c.nreg)
+        ops.gemm(w.patches, fz.wpatch, X, bias=fz.bpatch, pos=fz.pos, epi=EPI_PATCH, patch=(P, c.ntok, c.prefix),
+                 flags=OUT_F32)
+        scale = c.Dh ** -0.5
+        for l, b in enumerate(fz.blocks):
+            i = l if train else 0
+            xin = w.x_in[l] if train else w.x_in[0]
+            xmid = w.x_mid[i]
+            xout = w.x_in[l + 1] if train else w.x_in[0]
+            ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
+            if c.lora:
+                ops.skinny_xw(w.h1[i], pk.Acat[l], w.t[i], R=2 * c.rank)
+                ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv, a2=w.t[i], b2=pk.B2[l], K2=2 * c.rank)
+            else:
+                ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
+            ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale)
+            ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32)
+            ops.layernorm_fwd(xmid, b.n2w, b.n2b, w.h2, c.eps)
+            ops.gemm(w.h2, b.wfc1, w.g, bias=b.bfc1, aux=(w.u[l] if train else None),
+                     epi=EPI_SWIGLU if c.swiglu else EPI_GELU)
+            ops.gemm(w.g, b.wfc2, xout, bias=b.bfc2, gamma=b.ls2, aux=xmid, epi=EPI_RESID, flags=OUT_F32)
+        xf = w.x_in[c.L] if train else w.x_in[0]
+        ops.layernorm_fwd(xf, fz.nw, fz.nb, w.tok, c.eps)
+        return w.tok
+
+    def _bn(self, w, i, pk, conv_mod, count, bn_train):
+        bp, bn = w.bnp[i], conv_mod.bn
+        ops.bn_finalize(w.stats_f[i], pk.bn[i].w, pk.bn[i].b, bn.running_mean, bn.running_var, bp.scale, bp.shift,
+                        bp.mean, bp.rstd, pk.bn[i].w.numel(), NSLOTS, count, BN_EPS, BN_MOM, bn_train)
+
+    def _decoder_fwd(self, w, x, bn_train, pk, convs):
+        c = self._config()
+        B, D = w.B, c.D
+        S, s1, s2, s3, G = w.res
+        dev = x.device
+        mode = "bicubic" if c.patch != 16 else "identity"
+        ty = taps(mode, c.grid, G, dev)
+        ops.resample2d(w.tok[c.prefix:], w.feat, ty, ty, B=B, h=c.grid, w=c.grid, H=G, W=G, C=D, ld_src=D, ld_dst=D,
+                       src_bstride=c.ntok * D, dst_bstride=G * G * D)
+        ops.image_to_nhwc(x, w.img8, 8, nzero=5)
+        ld3 = w.cat[3].shape[-1]
+        ops.image_to_nhwc(x, w.cat[3].view(-1)[FUS_OUT[2]:], ld3, nzero=0)
+        # ConvStream: conv3x3 s2 -> BN -> ReLU, written into the skip slice of the matching concat buffer
+        src = [(w.img8, S, 8, 8), (w.cat[2], s1, 48, w.cat[2].shape[-1]), (w.cat[1], s2, 96, w.cat[1].shape[-1])]
+        dst = [(w.cat[2], s1), (w.cat[1], s2), (w.cat[0], s3)]
+        for i in range(3):
+            a, r_in, cin, ld = src[i]
+            d, r_out = dst[i]
+            Mo = B * r_out * r_out
+            cout = CONV_CH[i + 1]
+            if bn_train:
+                ops.gemm(a, pk.wk[i], w.pre_c[i], M=Mo, amode=A_CONV3, conv=(r_in, r_in, cin, ld, r_out, r_out, 2),
+                         epi=EPI_STATS, stats=w.stats_f[i], nslots=NSLOTS)
+            else:
+                ops.gemm(a, pk.wk[i], w.pre_c[i], M=Mo, amode=A_CONV3, conv=(r_in, r_in, cin, ld, r_out, r_out, 2))
+            self._bn(w, i, pk, convs[i], Mo, bn_train)
+            ops.bn_relu_apply(w.pre_c[i], w.bnp[i].scale, w.bnp[i].shift, d, Mo, cout, cout, d.shape[-1])
+        # Fusion blocks: bilinear x2 of the previous stage (BN+ReLU fused into the gather) -> concat slice -> conv3x3
+        tb = taps("bilinear", G, s3, dev)
+        ops.resample2d(w.feat, w.cat[0].view(-1)[CONV_CH[3]:], tb, tb, B=B, h=G, w=G, H=s3, W=s3, C=D, ld_src=D,
+                       ld_dst=w.cat[0].shape[-1], src_bstride=G * G * D, dst_bstride=s3 * s3 * w.cat[0].shape[-1])
+        res = [s3, s2, s1, S]
+        for j in range(4):
+            r = res[j]
+            Mo = B * r * r
+            cat = w.cat[j]
+            cp = cat.shape[-1]
+            i = 3 + j
+            if bn_train:
+                ops.gemm(cat, pk.wk[i], w.pre_f[j], M=Mo, amode=A_CONV3, conv=(r, r, cp, cp, r, r, 1), epi=EPI_STATS,
+                         stats=w.stats_f[i], nslots=NSLOTS)
+            else:
+                ops.gemm(cat, pk.wk[i], w.pre_f[j], M=Mo, amode=A_CONV3, conv=(r, r, cp, cp, r, r, 1))
+            self._bn(w, i, pk, convs[i], Mo, bn_train)
+            if j < 3:
+                nxt = w.cat[j + 1]
+                off = 0 if j == 2 else CONV_CH[2 - j]
+                t2 = taps("bilinear", r, 2 * r, dev)
+                ops.resample2d(w.pre_f[j], nxt.view(-1)[off:], t2, t2, B=B, h=r, w=r, H=2 * r, W=2 * r, C=FUS_OUT[j],
+                               ld_src=FUS_OUT[j], ld_dst=nxt.shape[-1], src_bstride=r * r * FUS_OUT[j],
+                               dst_bstride=4 * r * r * nxt.shape[-1], scale=w.bnp[i].scale, shift=w.bnp[i].shift)
+            else:
+                ops.bn_relu_apply(w.pre_f[3], w.bnp[i].scale, w.bnp[i].shift, w.F3, Mo, 32, 32, 32)
+        # heads
+        Mp = B * S * S
+        fl = self._flat
+        rm, rv = (fl.head_rm, fl.head_rv) if fl is not None else self._head_running()
+        if bn_train:
+            ops.heads_moments(w.F3, w.mom, Mp, NSLOTS)
+        ops.heads_bn_from_moments(w.mom, pk.W1, pk.b1, pk.bnw, pk.bnb, rm, rv, w.hbn.scale, w.hbn.shift, w.hbn.mean,
+                                  w.hbn.rstd, w.mom_sum, c.NH, NSLOTS, Mp, BN_EPS, BN_MOM, bn_train)
+        ops.heads_gate_fwd(w.F3, pk.W1, pk.b1, w.hbn.scale, w.hbn.shift, pk.W2, pk.b2, w.G, Mp, c.NH)
+        ops.heads_conv_fwd(w.F3, w.G, pk.W3k, pk.b3, w.out, B, S, S, c.NH)
+        return w.out
+
+    def _head_running(self):
+        """stacked running statistics of the head BatchNorms for a model whose parameters were not flattened"""
+        dev = self.device
+        heads = self._heads()
+        rm = torch.cat([h[0].psi[1].running_mean.detach().float() for h in heads]).to(dev).contiguous()
+        rv = torch.cat([h[0].psi[1].running_var.detach().float() for h in heads]).to(dev).contiguous()
+        return rm, rv
+
+    def forward(self, x, train=False, bn_train=None):
+        """Generator forward.  train=True keeps the activations the backward pass needs (one graph in flight)."""
+        dev = self._require_gpu()
+        c = self._config()
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != c.S or x.shape[3] != c.S:
+            raise ValueError(f"expected input [B,3,{c.S},{c.S}], got {tuple(x.shape)}")
+        in_dtype = x.dtype
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if bn_train is None:
+            bn_train = self.model.decoder.training
+        if train or bn_train or all(p.dtype == torch.float32 for p in self.model.decoder.parameters()):
+            self._ensure_flat()
+        pk = self._pack_trainable(need_bwd=train)
+        w = self._workspace(x.shape[0], train)
+        if bn_train:
+            w.arena_f.zero_()
+        dec = self.model.decoder
+        convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
+        self._encoder_fwd(w, x, train, pk)
+        out = self._decoder_fwd(w, x, bn_train, pk, convs)
+        if bn_train:
+            self._flat.nbt.add_(1)
+        if train:
+            self._saved = NS(w=w, pk=pk, x=x, convs=convs, bn_train=bn_train)
+        return out if in_dtype == torch.float32 else out.to(in_dtype)
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, w, i, src, r_in, cin_pad, ld, r_out, stride, dpre, cout):
+        """dW^T[(ky,kx,c), co] = sum_m Xcol^T[(ky,kx,c), m] * dY^T[co, m]  (split-K, f32 atomics)"""
+        B = w.B
+        Mo = B * r_out * r_out
+        K9 = 9 * cin_pad
+        xc = w.xcolT[:K9 * Mo].view(K9, Mo)
+        ops.im2col_t(src, xc, B, r_in, r_in, cin_pad, ld, r_out, r_out, stride)
+        dyT = w.dyT[:cout * Mo].view(cout, Mo)
+        ops.transpose_bf16(dpre, dyT, Mo, cout, cout, Mo)
+        tiles = ((K9 + 127) // 128) * max(1, (cout + 127) // 128)
+        ks = max(1, min(1024 // tiles, Mo // 512))
+        ops.gemm(xc, dyT, w.dWt[i], M=K9, N=cout, K=Mo, lda=Mo, ldb=Mo, ldc=cout, flags=OUT_F32 | ATOMIC, ksplit=ks)
+
+    def backward(self, dY, on_decoder_done=None):
+        """Gradients of every trainable parameter into the flat gradient buffer (views = param.grad)."""
+        sv = self._saved
+        if sv is None:
+            raise RuntimeError("backward() needs a preceding forward(train=True)")
+        if not sv.bn_train:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the training path")
+        c, fz, fl = self._config(), self._ensure_frozen_bwd(), self._ensure_flat()
+        if not c.lora:
+            raise NotImplementedError("training a fully unfrozen encoder is outside the MIPHEI-ViT (LoRA) hot path")
+        w, pk, convs = sv.w, sv.pk, sv.convs
+        B, D, M = w.B, c.D, w.M
+        S, s1, s2, s3, G = w.res
+        dev = dY.device
+        Mp = B * S * S
+        w.arena_b[:-2].zero_()
+        w.wscr.zero_()
+        fl.gflat.zero_()
+        dY = dY.to(torch.float32).contiguous()
+        # ---- heads
+        ops.heads_conv_bwd(dY, w.out, w.F3, w.G, pk.W3k, w.ET, w.dG, w.dXc, fl.db3, B, S, S, c.NH)
+        xT = w.dyT[:HEAD_C * Mp].view(HEAD_C, Mp)
+        ops.transpose_bf16(w.F3, xT, Mp, HEAD_C, HEAD_C, Mp)
+        ks = max(1, min(512, Mp // 512))
+        ops.gemm(w.ET, xT, w.dW3, M=c.NH * 9, N=HEAD_C, K=Mp, lda=Mp, ldb=Mp, ldc=HEAD_C, flags=OUT_F32 | ATOMIC, ksplit=ks)
+        fl.dW3.add_(w.dW3.view(c.NH, 9, HEAD_C).transpose(1, 2))
+        ops.heads_gate_bwd(w.F3, w.G, w.dG, w.dXc, pk.W1, pk.b1, w.hbn.scale, w.hbn.shift, w.hbn.mean, w.hbn.rstd, pk.bnw,
+                           pk.W2, w.mom_sum, w.hred, w.coef, fl.dW1, fl.dbnw, fl.dbnb, fl.dW2, fl.db2, w.dF3, Mp, c.NH,
+                           NSLOTS)
+        # ---- fusion blocks (reverse)
+        res = [s3, s2, s1, S]
+        dy_post, ld_post = w.dF3, HEAD_C
+        for j in (3, 2, 1, 0):
+            i, r = 3 + j, res[j]
+            Mo = B * r * r
+            cat = w.cat[j]
+            cp = cat.shape[-1]
+            cout = FUS_OUT[j]
+            bp = w.bnp[i]
+            bn = convs[i].bn
+            ops.bn_relu_bwd(dy_post, ld_post, w.pre_f[j], bp.scale, bp.shift, bp.mean, bp.rstd, pk.bn[i].w, w.stats_b[i],
+                            fl.gview[id(bn.weight)], fl.gview[id(bn.bias)], w.dpre_f[j], Mo, cout, NSLOTS)
+            self._wgrad(w, i, cat, r, cp, cp, r, 1, w.dpre_f[j], cout)
+            # dgrad into the concat-gradient buffer (fus3: only the 64 upsampled channels carry gradient)
+            ncols = FUS_OUT[2] if j == 3 else cp
+            dcat = w.dcat[j]
+            ops.gemm(w.dpre_f[j], pk.wd[i], dcat, M=Mo, N=ncols, amode=A_CONV3_T, conv=(r, r, cout, cout, r, r, 1),
+                     ldc=dcat.shape[-1])
+            if j > 0:
+                # adjoint of the bilinear x2 upsample -> gradient w.r.t. relu(BN(pre_f[j-1]))
+                off = 0 if j == 3 else CONV_CH[3 - j]
+                rp = res[j - 1]
+                cprev = FUS_OUT[j - 1]
+                ta = taps("bilinear", rp, r, dev, adjoint=True)
+                ops.resample2d(dcat.view(-1)[off:], w.dFpost[j - 1], ta, ta, B=B, h=r, w=r, H=rp, W=rp, C=cprev,
+                               ld_src=dcat.shape[-1], ld_dst=cprev, src_bstride=r * r * dcat.shape[-1],
+                               dst_bstride=rp * rp * cprev)
+                dy_post, ld_post = w.dFpost[j - 1], cprev
+        # ---- encoder feature gradient: adjoint bilinear (s3 -> G), adjoint regrid (G -> token grid)
+        dcat0 = w.dcat[0]
+        ta = taps("bilinear", G, s3, dev, adjoint=True)
+        ops.resample2d(dcat0.view(-1)[CONV_CH[3]:], w.dfeat, ta, ta, B=B, h=s3, w=s3, H=G, W=G, C=D, ld_src=dcat0.shape[-1],
+                       ld_dst=D, src_bstride=s3 * s3 * dcat0.shape[-1], dst_bstride=G * G * D)
+        mode = "bicubic" if c.patch != 16 else "identity"
+        tr = taps(mode, c.grid, G, dev, adjoint=True)
+        ops.resample2d(w.dfeat, w.dtok[c.prefix:], tr, tr, B=B, h=G, w=G, H=c.grid, W=c.grid, C=D, ld_src=D, ld_dst=D,
+                       src_bstride=G * G * D, dst_bstride=c.ntok * D)
+        # ---- ConvStream (reverse): dD_k = skip slice of the concat gradient (+ dgrad of the next conv, accumulated)
+        skip = [(w.dcat[2], s1), (w.dcat[1], s2), (w.dcat[0], s3)]
+        srcs = [(w.img8, S, 8, 8), (w.cat[2], s1, 48, w.cat[2].shape[-1]), (w.cat[1], s2, 96, w.cat[1].shape[-1])]
+        for i in (2, 1, 0):
+            dsk, r_out = skip[i]
+            Mo = B * r_out * r_out
+            cout = CONV_CH[i + 1]
+            bp, bn = w.bnp[i], convs[i].bn
+            ops.bn_relu_bwd(dsk, dsk.shape[-1], w.pre_c[i], bp.scale, bp.shift, bp.mean, bp.rstd, pk.bn[i].w, w.stats_b[i],
+                            fl.gview[id(bn.weight)], fl.gview[id(bn.bias)], w.dpre_c[i], Mo, cout, NSLOTS)
+            a, r_in, cin, ld = srcs[i]
+            self._wgrad(w, i, a, r_in, cin, ld, r_out, 2, w.dpre_c[i], cout)
+            if i > 0:
+                tgt, _ = skip[i - 1]
+                ops.gemm(w.dpre_c[i], pk.wd[i], tgt, M=B * r_in * r_in, N=cin, amode=A_CONV3_T,
+                         conv=(r_out, r_out, cout, cout, r_in, r_in, 2), ldc=tgt.shape[-1], flags=ACCUM_BF16)
+        # conv weight gradients: dWt [(ky,kx,c_pad), cout] -> parameter layout [cout, cin, ky, kx]
+        for i, cv in enumerate(convs):
+            cp, cin = pk.cin_pad[i], pk.cin[i]
+            g = w.dWt[i].view(3, 3, cp, -1)[:, :, :cin].permute(3, 2, 0, 1)
+            gw = fl.gview[id(cv.conv.weight)]
+            if pk.perm[i] is not None:
+                gw.index_copy_(1, pk.perm[i], g)
+            else:
+                gw.copy_(g)
+        if on_decoder_done is not None:
+            on_decoder_done()
+        # ---- encoder (LoRA gradients; frozen weights need dgrad only)
+        r_ = c.rank
+        scale = c.Dh ** -0.5
+        last = fz.blocks[c.L - 1]
+        ops.layernorm_bwd(w.dtok, w.x_in[c.L], fz.nw, w.dx, last.ls2, w.dy, c.eps, accumulate=False)
+        for l in range(c.L - 1, -1, -1):
+            b = fz.blocks[l]
+            # MLP branch: dy = ls2 * dx
+            ops.gemm(w.dy, b.t.wfc2, w.du, aux=w.u[l], epi=EPI_DSWIGLU if c.swiglu else EPI_DGELU)
+            ops.gemm(w.du, b.t.wfc1, w.dh)
+            ops.layernorm_bwd(w.dh, w.x_mid[l], b.n2w, w.dx, b.ls1, w.dy, c.eps, accumulate=True)
+            # attention branch: dy = ls1 * dx
+            ops.gemm(w.dy, b.t.wproj, w.do)
+            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, w.dqkv, B, c.ntok, c.H, c.Dh, scale)
+            dq, dv = w.dqkv, w.dqkv.view(-1)[2 * D:]
+            ops.skinny_xw(dq, pk.Bq[l], w.dt, ldx=3 * D, wsk=1, wsr=D, ldo=16, M=M, K=D, R=r_)
+            ops.skinny_xw(dv, pk.Bv[l], w.dt.view(-1)[r_:], ldx=3 * D, wsk=1, wsr=D, ldo=16, M=M, K=D, R=r_)
+            t = w.t[l]
+            ops.skinny_xty(t, dq, fl.dBq[l], ldx=16, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
+            ops.skinny_xty(t.view(-1)[r_:], dv, fl.dBv[l], ldx=16, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
+            ops.skinny_xty(w.dt, w.h1[l], fl.dAq[l], ldx=16, ldy=D, osr=1, osn=r_, M=M, N=D, R=r_)
+            ops.skinny_xty(w.dt.view(-1)[r_:], w.h1[l], fl.dAv[l], ldx=16, ldy=D, osr=1, osn=r_, M=M, N=D, R=r_)
+            if l > 0:
+                ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
+                ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)
+        if c.alpha != 1.0:
+            fl.dBq.mul_(c.alpha)
+            fl.dBv.mul_(c.alpha)
+        return fl.gflat
+
+    # ------------------------------------------------------------------ fused training step
+    def loss_and_grad(self, out, target, marker_weights, lambda_factor):
+        """WeightedMSELoss value (device scalar, f64) and dL/d(out) in the workspace."""
+        w = self._saved.w
+        w.loss_acc.zero_()
+        ops.wmse_fwd_bwd(out, target.to(torch.float32).contiguous(), marker_weights, w.loss_acc, w.dY, float(lambda_factor))
+        B, C, H, W = out.shape
+        return w.loss_acc * (float(lambda_factor) / (C * B * H * W)), w.dY
+
+    def adam_step(self, lr, betas=(0.5, 0.999), eps=1e-7, max_norm=1.0):
+        fl, w = self._flat, self._saved.w
+        if fl.m is None:
+            fl.m, fl.v = torch.zeros_like(fl.flat), torch.zeros_like(fl.flat)
+        fl.step += 1
+        w.sqn.zero_()
+        ops.sqnorm(fl.gflat, w.sqn)
+        ops.adam_clip_step(fl.flat, fl.gflat, fl.m, fl.v, w.sqn, float(lr), betas[0], betas[1], eps,
+                           1.0 - betas[0] ** fl.step, 1.0 - betas[1] ** fl.step, float(max_norm))
+        self._pack_key = None  # parameters changed in place through the flat buffer
+        return w.sqn
+
+    def grad_buckets(self):
+        """(decoder gradients, LoRA gradients): contiguous slices of the flat gradient buffer for all-reduce."""
+        fl = self._ensure_flat()
+        return fl.gflat[fl.n_lora:], fl.gflat[:fl.n_lora]
+
+    # ------------------------------------------------------------------ autograd bridge (generic callers)
+    def forward_autograd(self, x):
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
+        if not needs_grad:
+            return self.forward(x, train=False).clone()
+        fl = self._ensure_flat()
+        return _GeneratorFn.apply(self, x, *[p for p in fl.params if p.requires_grad])
+
+
+class _GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, x, *params):
+        ctx.engine = engine
+        ctx.n = len(params)
+        return engine.forward(x, train=True).clone()
+
+    @staticmethod
+    def backward(ctx, dY):
+        eng = ctx.engine
+        fl = eng._flat
+        keep = fl.gflat.clone()           # gradients accumulated by earlier backward calls (p.grad are views)
+        eng.backward(dY)
+        new = fl.gflat.clone()
+        fl.gflat.copy_(keep)
+        grads, o = [], 0
+        for p in fl.params:
+            k = p.numel()
+            if p.requires_grad:
+                grads.append(new[o:o + k].view(p.shape))
+            o += k
+        return (None, None, *grads)
+
+
+def encoder_tokens(vit, x):
+    """Encoder-only forward for a bare VisionTransformer (registry models used outside ViTMatte)."""
+    eng = vit.__dict__.get("_engine_owner")
+    if eng is None:
+        raise RuntimeError("encoder-only forward needs the ViT to be wrapped by ViTMatte (engine owner)")
+    dev = eng._require_gpu()
+    x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+    pk = eng._pack_trainable(need_bwd=False)
+    w = eng._workspace(x.shape[0], False)
+    c = eng._config()
+    tok = eng._encoder_fwd(w, x, False, pk)
+    return tok.view(x.shape[0], c.ntok, c.D).float()

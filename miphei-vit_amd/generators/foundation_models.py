@@ -1,0 +1,184 @@
+"""Pathology foundation-model encoders as parameter containers with timm's attribute / key layout.
+
+The reference builds its encoder with ``timm.create_model("vit_giant_patch14_reg4_dinov2", ...)``
+(``/root/reference/src/generators/foundation_models.py:50-57``); timm is not a dependency here.
+``VisionTransformer`` below holds the same parameters under the same state-dict names
+and exposes the attributes the reference reads (``patch_embed.{grid_size,patch_size,img_size}``,
+``num_prefix_tokens``, ``embed_dim``, ``no_embed_class``, ``blocks[i].attn.qkv``, ``set_input_size``);
+its arithmetic is executed by the HIP engine.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=True)
+        self.set_input_size(img_size)
+
+    def set_input_size(self, img_size):
+        img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        self.img_size = img_size
+        self.grid_size = (img_size[0] // self.patch_size[0], img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+
+
+class LayerScale(nn.Module):
+    def __init__(self, dim, init_values):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, 3 * dim, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    """fc1 -> act -> fc2; for SwiGLUPacked fc1 emits [a | b] and fc2 consumes silu(a)*b (hidden/2 wide)."""
+
+    def __init__(self, dim, hidden, swiglu):
+        super().__init__()
+        self.swiglu = swiglu
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden // 2 if swiglu else hidden, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, hidden, swiglu, init_values, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads)
+        self.ls1 = LayerScale(dim, init_values)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, hidden, swiglu)
+        self.ls2 = LayerScale(dim, init_values)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=14, embed_dim=1536, depth=40, num_heads=24, mlp="swiglu", hidden=8192,
+                 reg_tokens=4, init_values=1e-5, ln_eps=1e-6, global_pool=""):
+        super().__init__()
+        if mlp not in ("swiglu", "gelu"):
+            raise ValueError(mlp)
+        if mlp == "swiglu" and hidden % 2:
+            raise ValueError("SwiGLUPacked needs an even hidden size")
+        self.embed_dim = self.num_features = embed_dim
+        self.num_heads = num_heads
+        self.mlp_type = mlp
+        self.hidden = hidden
+        self.ln_eps = ln_eps
+        self.reg_tokens = reg_tokens
+        self.num_prefix_tokens = 1 + reg_tokens
+        self.no_embed_class = True
+        self.global_pool = global_pool
+        self.patch_embed = PatchEmbed(img_size, patch_size, 3, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.reg_token = nn.Parameter(torch.zeros(1, reg_tokens, embed_dim)) if reg_tokens else None
+        self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches, embed_dim) * 0.02)
+        self.blocks = nn.ModuleList(
+            [Block(embed_dim, num_heads, hidden, mlp == "swiglu", init_values, ln_eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=ln_eps)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        if reg_tokens:
+            nn.init.normal_(self.reg_token, std=1e-6)
+
+    def set_input_size(self, img_size=None, patch_size=None):
+        """Re-grid the position embedding for a new input size (timm resample_abs_pos_embed semantics)."""
+        if img_size is None:
+            return
+        old = self.patch_embed.grid_size
+        self.patch_embed.set_input_size(img_size)
+        new = self.patch_embed.grid_size
+        if new != old:
+            self.pos_embed = nn.Parameter(_resample_pos_embed(self.pos_embed.data, old, new),
+                                          requires_grad=self.pos_embed.requires_grad)
+        eng = getattr(self, "_engine_owner", None)
+        if eng is not None:
+            eng.invalidate()
+
+    def forward(self, x):
+        """Encoder-only tokens [B, N, D] (global_pool='', no head) through the HIP engine."""
+        from ..engine import encoder_tokens
+        return encoder_tokens(self, x)
+
+
+def _resample_pos_embed(posemb, old_grid, new_grid):
+    """bicubic + antialias re-grid in fp32 (load-time only; reference: foundation_models.py:198-208)."""
+    D = posemb.shape[-1]
+    p = posemb.float().reshape(1, old_grid[0], old_grid[1], D).permute(0, 3, 1, 2)
+    p = F.interpolate(p, size=new_grid, mode="bicubic", antialias=True)
+    return p.permute(0, 2, 3, 1).reshape(1, new_grid[0] * new_grid[1], D).to(posemb.dtype)
+
+
+def resize_pos_embed_statedict(state_dict, model, img_size):
+    if "pos_embed" in state_dict:
+        g = model.patch_embed.grid_size
+        pe = state_dict["pos_embed"]
+        n_old = pe.shape[1]
+        side = int(math.sqrt(n_old))
+        if side * side != n_old:  # checkpoints that carry a class-token slot
+            pe = pe[:, n_old - int(math.sqrt(n_old - 1)) ** 2:]
+            side = int(math.sqrt(pe.shape[1]))
+        if (side, side) != tuple(g):
+            pe = _resample_pos_embed(pe, (side, side), tuple(g))
+        state_dict["pos_embed"] = pe
+    return state_dict
+
+
+def _load_checkpoint(model, ckpt_path, img_size):
+    if str(ckpt_path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(str(ckpt_path))
+    else:
+        sd = torch.load(str(ckpt_path), map_location="cpu")
+    sd = resize_pos_embed_statedict(dict(sd), model, img_size)
+    model.load_state_dict(sd)
+
+
+def _build(img_size, pretrained, ckpt_path, name, **kw):
+    model = VisionTransformer(img_size=img_size, **kw)
+    if ckpt_path is not None:
+        _load_checkpoint(model, ckpt_path, img_size)
+    elif pretrained and os.environ.get("MIPHEI_RANDOM_INIT", "0") != "1":
+        raise RuntimeError(
+            f"{name}: no checkpoint given (cfg.model.encoder.encoder_weights) and the Hugging Face hub is not reachable; "
+            "pass ckpt_path, or pretrained=False / MIPHEI_RANDOM_INIT=1 for randomly initialised weights")
+    return model
+
+
+def hoptimus0(img_size, pretrained=True, ckpt_path=None, drop_path_rate=0., global_pool=""):
+    """H-Optimus-0 = vit_giant_patch14_reg4_dinov2 (reference foundation_models.py:50-69)."""
+    return _build(img_size, pretrained, ckpt_path, "hoptimus0", patch_size=14, embed_dim=1536, depth=40, num_heads=24,
+                  mlp="swiglu", hidden=8192, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+
+
+def tiny_gelu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
+    """BASELINE.json config 1 'Tiny-ViT (2 layers, 64-d)': patch16 D64 L2 H4 GELU (not in the reference registry)."""
+    return _build(img_size, False, ckpt_path, "tiny", patch_size=16, embed_dim=64, depth=2, num_heads=4, mlp="gelu",
+                  hidden=256, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+
+
+def tiny_swiglu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
+    return _build(img_size, False, ckpt_path, "tiny_swiglu", patch_size=14, embed_dim=96, depth=2, num_heads=3,
+                  mlp="swiglu", hidden=512, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+
+
+FOUNDATION_MODEL_REGISTRY = {
+    "hoptimus0": hoptimus0,
+    "tiny": tiny_gelu,
+    "tiny_swiglu": tiny_swiglu,
+}

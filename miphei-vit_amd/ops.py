@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,  # noqa: F401
+from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,  # noqa: F401
                    EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
 
 
@@ -126,3 +126,83 @@ def attention_fwd(qkv, out, lse, B, N, H, Dh, scale):
 def attention_bwd(qkv, out, d_out, lse, dsum, dqkv, B, N, H, Dh, scale):
     _call("mvit_attention_bwd", _p(qkv), _p(out), _p(d_out), _p(lse), _p(dsum), _p(dqkv), B, N, H, Dh, scale)
     return dqkv
+
+
+# ------------------------------------------------------------------ decoder / heads / optimiser wrappers
+def resample2d(src, dst, taps_y, taps_x, *, B, h, w, H, W, C, ld_src, ld_dst, src_bstride, dst_bstride, scale=None,
+               shift=None):
+    (yi, yw), (xi, xw) = taps_y, taps_x
+    assert yi.shape[1] == xi.shape[1]
+    _call("mvit_resample2d", _p(src), _p(dst), _p(yi), _p(yw), _p(xi), _p(xw), _p(scale), _p(shift), B, h, w, H, W, C,
+          ld_src, ld_dst, src_bstride, dst_bstride, yi.shape[1])
+
+
+def image_to_nhwc(img, dst, ld_dst, nzero=0):
+    B, Cc, S, _ = img.shape
+    _call("mvit_image_to_nhwc", _p(img), _p(dst), B, S, Cc, ld_dst, nzero)
+
+
+def bn_finalize(stats, gamma, beta, rmean, rvar, scale, shift, mean, rstd, C_, nslots, count, eps, momentum, training):
+    _call("mvit_bn_finalize", _p(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(scale), _p(shift), _p(mean),
+          _p(rstd), C_, nslots, float(count), eps, momentum, int(training))
+
+
+def bn_relu_apply(x, scale, shift, out, M, C_, ld_x, ld_out):
+    _call("mvit_bn_relu_apply", _p(x), _p(scale), _p(shift), _p(out), M, C_, ld_x, ld_out)
+
+
+def bn_relu_bwd(dy, ld_dy, x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta, dx, M, C_, nslots):
+    _call("mvit_bn_relu_bwd_reduce", _p(dy), ld_dy, _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), M, C_,
+          nslots)
+    _call("mvit_bn_relu_bwd_apply", _p(dy), ld_dy, _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(gamma), _p(stats),
+          _p(dgamma), _p(dbeta), _p(dx), M, C_, nslots, float(M))
+
+
+def transpose_bf16(src, dst, R, Cc, ld_src, ld_dst):
+    _call("mvit_transpose_bf16", _p(src), _p(dst), R, Cc, ld_src, ld_dst)
+
+
+def im2col_t(x, out, B, H, W, C_, ld, OH, OW, stride):
+    _call("mvit_im2col_t", _p(x), _p(out), B, H, W, C_, ld, OH, OW, stride)
+
+
+def heads_moments(x, mom, M, nslots):
+    _call("mvit_heads_moments", _p(x), _p(mom), M, nslots)
+
+
+def heads_bn_from_moments(mom, W1, b1, gamma, beta, rmean, rvar, scale, shift, mean, rstd, mom_sum, NH, nslots, count,
+                          eps, momentum, training):
+    _call("mvit_heads_bn_from_moments", _p(mom), _p(W1), _p(b1), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(scale),
+          _p(shift), _p(mean), _p(rstd), _p(mom_sum), NH, nslots, float(count), eps, momentum, int(training))
+
+
+def heads_gate_fwd(x, W1, b1, scale, shift, W2, b2, G, M, NH):
+    _call("mvit_heads_gate_fwd", _p(x), _p(W1), _p(b1), _p(scale), _p(shift), _p(W2), _p(b2), _p(G), M, NH)
+
+
+def heads_conv_fwd(x, G, W3, b3, out, B, H, W, NH):
+    _call("mvit_heads_conv_fwd", _p(x), _p(G), _p(W3), _p(b3), _p(out), B, H, W, NH)
+
+
+def heads_conv_bwd(dY, Y, x, G, W3, ET, dG, dXc, db3, B, H, W, NH):
+    _call("mvit_heads_conv_bwd", _p(dY), _p(Y), _p(x), _p(G), _p(W3), _p(ET), _p(dG), _p(dXc), _p(db3), B, H, W, NH)
+
+
+def heads_gate_bwd(x, G, dG, dXc, W1, b1, scale, shift, mean, rstd, gamma, W2, mom_sum, red, coef, dW1, dgamma, dbeta, dW2,
+                   db2, dF, M, NH, nslots):
+    _call("mvit_heads_gate_bwd", _p(x), _p(G), _p(dG), _p(dXc), _p(W1), _p(b1), _p(scale), _p(shift), _p(mean), _p(rstd),
+          _p(gamma), _p(W2), _p(mom_sum), _p(red), _p(coef), _p(dW1), _p(dgamma), _p(dbeta), _p(dW2), _p(db2), _p(dF), M,
+          NH, nslots, float(M))
+
+
+def wmse_fwd_bwd(pred, target, w, loss_acc, dY, lambda_factor):
+    B, Cc, H, W = pred.shape
+    _call("mvit_wmse_fwd_bwd", _p(pred), _p(target), _p(w), _p(loss_acc), _p(dY), B, Cc, H * W, lambda_factor)
+
+
+def sqnorm(x, out):
+    _call("mvit_sqnorm", _p(x), _p(out), x.numel())
+
+
+def adam_clip_step(p, g, m, v, sqn, lr, beta1, beta2, eps, bc1, bc2, max_norm):
+    _call("mvit_adam_clip_step", _p(p), _p(g), _p(m), _p(v), _p(sqn), p.numel(), lr, beta1, beta2, eps, bc1, bc2, max_norm)
