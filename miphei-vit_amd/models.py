@@ -1,0 +1,136 @@
+"""``ModelModule``: the training / prediction step around the generator.
+
+Mirrors the constructor and step methods of the reference LightningModule (``/root/reference/src/models.py``:
+``__init__`` :22-73, ``forward`` :75-76, ``predict_step`` :78-79, ``training_step`` :87-143 non-GAN branch,
+``configure_optimizers`` :348-371).  pytorch_lightning is optional: when it is importable the class derives from
+``LightningModule`` (manual optimisation, as the reference); otherwise from ``nn.Module`` and ``fit`` / ``predict`` in
+``trainer.py`` drive it.
+
+The non-GAN ``training_step`` runs as ONE fused device sequence: HIP generator forward -> fused WeightedMSE loss +
+gradient -> HIP backward -> (optional) RCCL all-reduce of the two gradient buckets, the decoder bucket overlapped
+with the encoder backward -> global-norm clip + Adam on the flat parameter buffer -> LR schedule.  The reference's
+per-step host sync (``torch.isnan(fake).any()``, models.py:102-105) becomes an asynchronous check of the loss scalar.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .loss import WeightedMSELoss
+from .utils import pix2pix_lr_scheduler
+
+try:  # pragma: no cover - not installed in the build container
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    pl = None
+    _Base = nn.Module
+
+
+class ModelModule(_Base):
+    def __init__(self, generator, discriminator, lr_g, lr_d, loss_reconstruct, cell_metrics=None, cell_loss=None,
+                 gan_train=False):
+        super().__init__()
+        if gan_train or discriminator is not None and gan_train:
+            raise NotImplementedError("the PatchGAN branch is outside the MI355X hot path (gan_train: false is the "
+                                      "MIPHEI-ViT default)")
+        if cell_metrics is not None or cell_loss is not None:
+            raise NotImplementedError("cell-level metrics / losses are outside the MI355X hot path")
+        self.generator = generator
+        self.foreground_head = hasattr(generator, "foreground_head")
+        self.discriminator = None
+        self.gan_train = False
+        self.automatic_optimization = False
+        self.use_cell_metrics = False
+        self.lr_g, self.lr_d = lr_g, lr_d
+        self.loss_reconstruct = loss_reconstruct
+        self.vit_lr_decay = False
+        # fused-step state
+        self.total_iters = None
+        self.global_step_ = 0
+        self.nan_check_every = 50
+        self._pending_loss = None
+        self.grad_sync = None  # set by trainer.DataParallelSync for multi-GPU runs
+        self.last_loss = None
+
+    # ------------------------------------------------------------------ inference
+    def forward(self, inputs):
+        return self.generator(inputs)
+
+    def predict_step(self, batch, batch_idx=0):
+        return self.generator(batch["image"])
+
+    # ------------------------------------------------------------------ optimiser surface (reference parity)
+    def configure_optimizers(self):
+        """torch Adam + LambdaLR exactly as the reference builds them (used by generic / Lightning callers;
+        the fused ``training_step`` applies the same update rule in one HIP launch)."""
+        g_optimizer = torch.optim.Adam(self.generator.parameters(), lr=self.lr_g, betas=(0.5, 0.999), eps=1e-7)
+        total_iters = self._total_iters()
+        g_scheduler = {
+            "scheduler": torch.optim.lr_scheduler.LambdaLR(
+                g_optimizer, lr_lambda=pix2pix_lr_scheduler(total_iters, 400, total_iters // 2)),
+            "interval": "step", "frequency": 1}
+        return [g_optimizer], [g_scheduler]
+
+    def _total_iters(self):
+        if self.total_iters is not None:
+            return int(self.total_iters)
+        tr = getattr(self, "_trainer", None) or getattr(self, "trainer", None)
+        if tr is not None and hasattr(tr, "estimated_stepping_batches"):
+            return int(tr.estimated_stepping_batches)
+        raise RuntimeError("set ModelModule.total_iters (or attach a trainer exposing estimated_stepping_batches)")
+
+    def current_lr(self, step=None):
+        step = self.global_step_ if step is None else step
+        total = self._total_iters()
+        return self.lr_g * pix2pix_lr_scheduler(total, 400, total // 2)(step)
+
+    # ------------------------------------------------------------------ fused training step
+    def training_step(self, batch, batch_idx=0):
+        x, y = batch["image"], batch["target"]
+        eng = getattr(self.generator, "_engine", None)
+        if eng is None or not isinstance(self.loss_reconstruct, WeightedMSELoss):
+            raise NotImplementedError("the fused step needs a MIPHEI-ViT generator and WeightedMSELoss")
+        self.generator.train()
+        out = eng.forward(x, train=True)
+        w = self.loss_reconstruct.marker_weights
+        if w.device != out.device:
+            self.loss_reconstruct.to(out.device)
+            w = self.loss_reconstruct.marker_weights
+        loss, dY = eng.loss_and_grad(out, y.to(out.device), w, self.loss_reconstruct.lambda_factor)
+        sync = self.grad_sync
+        eng.backward(dY, on_decoder_done=(sync.decoder_ready if sync is not None else None))
+        if sync is not None:
+            sync.finish()
+        eng.adam_step(self.current_lr(), betas=(0.5, 0.999), eps=1e-7, max_norm=1.0)
+        self.global_step_ += 1
+        self.last_loss = loss
+        self._nan_guard(loss)
+        return loss
+
+    def _nan_guard(self, loss):
+        """Asynchronous form of the reference's NaN guard: a NaN/Inf anywhere in the generator output makes the loss
+        non-finite; the device scalar is copied out without blocking and inspected ``nan_check_every`` steps later."""
+        if self.global_step_ % self.nan_check_every == 0:
+            if self._pending_loss is not None:
+                ev, host = self._pending_loss
+                ev.synchronize()
+                if not math.isfinite(float(host)):
+                    torch.save(self.state_dict(), "weights_nan.ckpt")
+                    raise ValueError("Nan found")
+            host = torch.empty(1, dtype=torch.float64, pin_memory=True)
+            host.copy_(loss.detach(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending_loss = (ev, host)
+
+    def validation_step(self, batch, batch_idx=0):
+        self.generator.eval()
+        with torch.no_grad():
+            out = self.generator(batch["image"])
+            return self.loss_reconstruct(batch["target"].to(out.device), out)
+
+    def test_step(self, batch, batch_idx=0):
+        return self.validation_step(batch, batch_idx)

@@ -85,17 +85,28 @@ def test_backward_matches_oracle_autograd(cfgname, img, nc, B):
     loss = weighted_mse_loss(y.cuda(), out, w.cuda())
     loss.backward()
     assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref))
+    # yardstick: the same arithmetic under bf16 autocast (the reference's mixed-precision mode) vs fp32 on CPU.
+    # The HIP path (bf16 operands, f32 accumulate) must not be noisier than that, per parameter.
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, _, gac = tr.loss_and_grads(x, y)
     named = dict(model.named_parameters())
-    worst = {}
+    gnorm = float(torch.cat([g.flatten().double() for g in gref.values()]).norm())
+    bad = {}
     for k, gr in gref.items():
         got = named[k].grad
         assert got is not None, k
-        worst[k] = _rel(got, gr)
-    bad = {k: v for k, v in worst.items() if v > 6e-2}
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
-    # global direction
-    gv = torch.cat([named[k].grad.flatten().cpu().double() for k in gref])
-    rv = torch.cat([gref[k].flatten().double() for k in gref])
+        if float(gr.double().norm()) < 1e-5 * gnorm:   # analytically zero (bias in front of a train-mode BatchNorm)
+            assert float(got.double().norm()) < 1e-5 * gnorm, k
+            continue
+        e_hip, e_ac = _rel(got, gr), _rel(gac[k], gr)
+        if e_hip > max(1.25 * e_ac, 0.02):
+            bad[k] = (e_hip, e_ac)
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12]
+    keys = [k for k in gref if float(gref[k].double().norm()) >= 1e-5 * gnorm]
+    gv = torch.cat([named[k].grad.flatten().cpu().double() for k in keys])
+    rv = torch.cat([gref[k].flatten().double() for k in keys])
+    av = torch.cat([gac[k].flatten().double() for k in keys])
     cos = float((gv * rv).sum() / (gv.norm() * rv.norm()))
-    assert cos > 0.999, cos
+    cos_ac = float((av * rv).sum() / (av.norm() * rv.norm()))
+    assert cos > min(0.9995, cos_ac), (cos, cos_ac)
     assert abs(float(gv.norm() / rv.norm()) - 1) < 2e-2
