@@ -1,0 +1,209 @@
+"""Headline benchmark: MIPHEI-ViT training tiles/s (256x256 H&E -> 16-channel mIF) on N MI355X of one node.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one ModelModule.training_step on one synthetic minibatch per rank: HIP generator forward (H-Optimus-0 ViT-g/14
+encoder with LoRA + ViTMatte decoder, bf16 MFMA / f32 accumulate), fused WeightedMSE, HIP backward, gradient
+all-reduce (RCCL) when N>1, global-norm clip + Adam.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the dense 128x128 MFMA GEMM
+with the plain store epilogue; algorithmic flops / HIP-event durations recorded live during the timed steps) and
+`cpu_baseline` (the CPU oracle = port of the reference arithmetic, timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOPS_TRAIN = {256: 1647.2e9, 512: 7604.0e9}   # SURVEY.md section 8(d), per tile
+FLOPS_FWD = {256: 793.4e9, 512: 3449.1e9}
+PEAK_BF16 = 2.5e15                                # dense MFMA bf16, MI355X_MICROARCH.md
+
+
+def synthetic_init_(model, seed):
+    """Random weights of the H-Optimus-0 + MIPHEI decoder architecture: linears N(0,1/sqrt(fan_in)),
+    convs N(0,0.02), LayerScale 0.5, LoRA A~N(0,1/8) B~N(0,0.02) (live adapters), norms ~ N(1,0.02)/N(0,0.02)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "gamma":
+                p.fill_(0.5)
+            elif leaf == "A":
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") / p.shape[1] ** 0.5)
+            elif leaf == "B":
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") * 0.02)
+            elif leaf in ("cls_token", "reg_token", "pos_embed"):
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") * 0.02)
+            elif leaf == "weight" and p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") / p.shape[1] ** 0.5)
+            elif leaf == "weight" and p.dim() == 4:
+                if "patch_embed" in name:
+                    p.copy_(torch.randn(p.shape, generator=g, device="cuda") / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5)
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g, device="cuda") * 0.02)
+            elif leaf == "weight":
+                p.copy_(1.0 + torch.randn(p.shape, generator=g, device="cuda") * 0.02)
+            elif leaf == "bias":
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") * 0.02)
+
+
+def synthetic_batch(seed, B, S, nc, device):
+    """H&E-like normalised image and mIF-like target, generated on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    mu = torch.tensor([211.1, 194.7, 213.8], device=device).view(1, 3, 1, 1)
+    sd = torch.tensor([30.1, 36.4, 26.4], device=device).view(1, 3, 1, 1)
+    rgb = (mu + sd * torch.randn(B, 3, S, S, generator=g, device=device)).round().clamp(0, 255)
+    mean = torch.tensor([0.707223, 0.578729, 0.703617], device=device).view(1, 3, 1, 1) * 255
+    std = torch.tensor([0.211883, 0.230117, 0.177517], device=device).view(1, 3, 1, 1) * 255
+    image = (rgb - mean) / std
+    u = torch.rand(B, nc, S, S, generator=g, device=device).clamp_min(1e-12)
+    t8 = (-20.0 * u.log()).floor().clamp(max=255)
+    target = t8 / 255.0 * 1.8 - 0.9
+    return image.contiguous(), target.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (cfg.train.batch_size of the reference)")
+    ap.add_argument("--img", type=int, default=256)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--encoder", default="hoptimus0")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from miphei_vit_amd import ops
+    from miphei_vit_amd.generators import get_vitmatte
+    from miphei_vit_amd.loss import WeightedMSELoss
+    from miphei_vit_amd.models import ModelModule
+    from miphei_vit_amd.trainer import DataParallelSync
+
+    nc = 16
+    weights = torch.tensor([1.0, 6.9687, 1.4698, 3.5986, 2.4121, 10.5982, 4.4980, 2.7238, 4.5266, 3.0473, 2.8660, 3.5367,
+                            1.7173, 3.6613, 1.5315, 2.5265])
+    with torch.device(dev):
+        model = get_vitmatte(a.encoder, a.img, nc, use_lora=True, pretrained=False)
+    synthetic_init_(model, seed=0)
+    eng = model._engine
+    mod = ModelModule(model, None, 2e-4 * a.batch ** 0.5, 0., WeightedMSELoss(50.0, weights)).to(dev)
+    mod.total_iters = 100000
+    mod.nan_check_every = 10 ** 9   # the guard's host copy is exercised in tests, not inside the timed region
+    if world > 1:
+        sync = DataParallelSync(eng)
+        sync.broadcast_parameters(0)
+        mod.grad_sync = sync
+    batches = [synthetic_batch(1234 + rank * 1000 + i, a.batch, a.img, nc, dev) for i in range(4)]
+
+    def step(i):
+        x, y = batches[i % len(batches)]
+        if a.mode == "train":
+            mod.training_step({"image": x, "target": y}, i)
+        else:
+            eng.forward(x, train=False, bn_train=False)
+
+    if a.mode == "infer":
+        model.eval()
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.PROBE.start()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    probe = ops.PROBE.stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    tiles = world * a.batch * a.steps
+    value = tiles / dt
+    flops_tile = (FLOPS_TRAIN if a.mode == "train" else FLOPS_FWD).get(a.img)
+
+    res = {
+        "metric": "training tiles/sec (256x256 H&E->16ch mIF)" if a.mode == "train" else "inference tiles/sec",
+        "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) {a.mode} step, "
+                               f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} (BASELINE.json configs[1])",
+                   "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}"},
+    }
+    if flops_tile:
+        res["model_flops_frac"] = round(value / world * flops_tile / PEAK_BF16, 4)
+    if rank == 0:
+        if probe["n"]:
+            ach = probe["flops"] / (probe["ms"] * 1e-3)
+            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<128,128,2,2,DENSE,STORE>",
+                               "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16, 4), "traffic": None, "launches": probe["n"],
+                               "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
+        if not a.no_cpu_baseline and world == 1 and a.mode == "train":
+            res["cpu_baseline"], res["parity"] = cpu_baseline(model, a, nc, weights, dev)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, a, nc, weights, dev):
+    """Time the CPU oracle (port of the reference arithmetic, fp32, all host cores) on a bounded sample -- one training
+    step (forward+backward) at batch `--cpu-batch` of the same workload and weights -- and report the GPU output's parity
+    against it on that sample (eval of the same inputs through the HIP forward with batch statistics)."""
+    from oracle import VIT_CONFIGS
+    from oracle.model import OracleTrainer
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = VIT_CONFIGS[a.encoder]
+    p = {k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()}
+    B = a.cpu_batch
+    x, y = synthetic_batch(999, B, a.img, nc, dev)
+    tr = OracleTrainer(p, cfg, nc, batch_size=B, total_iters=100000, weights=weights)
+    tr.p = p  # no second copy of the 4.6 GB state
+    t0 = time.perf_counter()
+    out_ref, loss_ref, _ = tr.loss_and_grads(x.cpu(), y.cpu())
+    dt = time.perf_counter() - t0
+    model.train()
+    with torch.no_grad():
+        out = model._engine.forward(x, train=False, bn_train=True).float().cpu()
+    rel = ((out - out_ref) ** 2).sum(dim=(0, 2, 3)) / (out_ref ** 2).sum(dim=(0, 2, 3))
+    xm, ym = out - out.mean(dim=(0, 2, 3), keepdim=True), out_ref - out_ref.mean(dim=(0, 2, 3), keepdim=True)
+    pear = (xm * ym).sum(dim=(0, 2, 3)) / ((xm ** 2).sum(dim=(0, 2, 3)).sqrt() * (ym ** 2).sum(dim=(0, 2, 3)).sqrt())
+    base = {"value": round(B / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step (fwd+bwd, fp32) of the CPU oracle at batch {B}, same weights, {dt:.1f} s"}
+    parity = {"worst_channel_rel_mse": float(rel.max()), "min_pearson_r": float(pear.min()), "tolerance_rel_mse": 1e-3,
+              "batch": B}
+    return base, parity
+
+
+if __name__ == "__main__":
+    main()

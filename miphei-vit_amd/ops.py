@@ -10,6 +10,26 @@ from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, ACCUM_BF16, ATOMIC, EPI_DGELU, E
                    EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
 
 
+class _Probe:
+    """Optional HIP-event timing of the dominant kernel (dense 128x128 MFMA GEMM, plain store epilogue) for bench.py."""
+
+    def __init__(self):
+        self.on = False
+        self.events = []
+
+    def start(self):
+        self.on, self.events = True, []
+
+    def stop(self):
+        self.on = False
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
+        return {"n": len(self.events), "ms": ms, "flops": float(sum(f for _, _, f in self.events))}
+
+
+PROBE = _Probe()
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -64,7 +84,14 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     if patch is not None:
         g.patch_P, g.patch_ntok, g.patch_prefix = patch
     g.epi, g.flags, g.ksplit, g.amode = epi, flags, ksplit, amode
+    probe = PROBE.on and amode == A_DENSE and epi == EPI_STORE and ksplit == 1 and (g.N % 128 == 0 or g.N >= 256)
+    if probe:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.lib().mvit_gemm_bf16(C.byref(g), _stream()), "mvit_gemm_bf16")
+    if probe:
+        e1.record()
+        PROBE.events.append((e0, e1, 2.0 * g.M * g.N * (g.K + g.K2)))
     return c
 
 

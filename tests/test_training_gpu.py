@@ -53,6 +53,8 @@ def test_training_steps_match_reference(golden_dir, name):
         # parameters moved by 3 Adam steps: compare the displacement as well as the value
         assert _rel(mine, ref) < 1e-3, k
     for k, v in tr.p.items():
+        if k.endswith("psi.0.bias"):
+            continue  # bias in front of a train-mode BatchNorm: exact gradient is 0 (the reference moves it by fp noise only)
         if k in named and named[k].requires_grad:
             d_ref = v - p[k]
             d_got = named[k].detach().cpu() - p[k]
