@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--encoder", default="hoptimus0")
     a = ap.parse_args()
 
@@ -181,7 +182,7 @@ def cpu_baseline(model, a, nc, weights, dev):
     against it on that sample (eval of the same inputs through the HIP forward with batch statistics)."""
     from oracle import VIT_CONFIGS
     from oracle.model import OracleTrainer
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, a.cpu_threads)   # torch-CPU GEMMs stop scaling (and collapse) far below 256 threads
     torch.set_num_threads(cores)
     cfg = VIT_CONFIGS[a.encoder]
     p = {k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()}

@@ -484,6 +484,7 @@ extern "C" {
 
 MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int Dh, float scale,
                                 mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream,
@@ -493,6 +494,7 @@ MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, i
 
 MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum,
                                 void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
   hipStream_t s = (hipStream_t)stream;

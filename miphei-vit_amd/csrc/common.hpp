@@ -51,3 +51,6 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 
 static inline int hip_ok(hipError_t e) { return e == hipSuccess ? MVIT_OK : (int)e; }
 #define MVIT_LAUNCH_CHECK() hip_ok(hipGetLastError())
+// hipGetLastError() reports (and resets) the last error of ANY earlier HIP call of this thread, including benign
+// probes made by other libraries in the process: reset it on entry so the check after our launch is about our launch.
+#define MVIT_CLEAR_ERROR() (void)hipGetLastError()

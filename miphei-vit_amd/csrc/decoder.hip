@@ -285,6 +285,7 @@ MVIT_API int mvit_resample2d(const void* src, void* dst, const int* ty_idx, cons
                              const float* tx_w, const float* scale, const float* shift, int B, int h, int w, int H, int W,
                              int C, int ld_src, int ld_dst, long long src_bstride, long long dst_bstride, int T,
                              mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || C <= 0 || (C & 7) || (ld_src & 7) || (ld_dst & 7) || T <= 0 || T > 16) return MVIT_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return MVIT_EINVAL;
   ResampleArgs a{(const bf16_t*)src, (bf16_t*)dst, ty_idx, ty_w, tx_idx, tx_w, scale, shift, B, h, w, H, W, C,
@@ -295,6 +296,7 @@ MVIT_API int mvit_resample2d(const void* src, void* dst, const int* ty_idx, cons
 
 MVIT_API int mvit_image_to_nhwc(const float* img, void* dst, int B, int S, int C, int ld_dst, int nzero,
                                 mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || S <= 0 || C <= 0 || C + nzero > ld_dst) return MVIT_EINVAL;
   hipLaunchKernelGGL(image_to_nhwc_kernel, dim3(nblk((long long)B * S * S, 256)), dim3(256), 0, (hipStream_t)stream, img,
                      (bf16_t*)dst, B, S, C, ld_dst, nzero);
@@ -304,6 +306,7 @@ MVIT_API int mvit_image_to_nhwc(const float* img, void* dst, int B, int S, int C
 MVIT_API int mvit_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
                               int nslots, double count, float eps, float momentum, int training, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (C <= 0 || (training && (!stats || nslots <= 0 || count <= 0))) return MVIT_EINVAL;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, gamma, beta,
                      running_mean, running_var, scale, shift, mean_out, rstd_out, C, nslots, count, eps, momentum, training);
@@ -312,6 +315,7 @@ MVIT_API int mvit_bn_finalize(const double* stats, const float* gamma, const flo
 
 MVIT_API int mvit_bn_relu_apply(const void* x, const float* scale, const float* shift, void* out, long long M, int C,
                                 int ld_x, int ld_out, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || (C & 7) || (ld_x & 7) || (ld_out & 7)) return MVIT_EINVAL;
   hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(nblk(M * (C >> 3), 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, scale, shift, (bf16_t*)out, M, C, ld_x, ld_out);
@@ -321,6 +325,7 @@ MVIT_API int mvit_bn_relu_apply(const void* x, const float* scale, const float* 
 MVIT_API int mvit_bn_relu_bwd_reduce(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
                                      const float* mean, const float* rstd, double* stats, long long M, int C, int nslots,
                                      mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || (C & 7) || C > 256 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
   const int rpb = 256 / (C >> 3);
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk(M, rpb * 16, 2048)), dim3(256), 0, (hipStream_t)stream,
@@ -332,6 +337,7 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
                                     const float* mean, const float* rstd, const float* gamma, const double* stats,
                                     float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
                                     mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || (C & 7) || C > 256 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(nblk(M * (C >> 3), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta,
@@ -341,6 +347,7 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
 
 MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int ld_src, long long ld_dst,
                                  mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (R <= 0 || Cc <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(transpose_kernel, dim3((R + 63) / 64, (Cc + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, (bf16_t*)dst, R, Cc, ld_src, ld_dst);
@@ -349,6 +356,7 @@ MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int 
 
 MVIT_API int mvit_im2col_t(const void* x, void* out, int B, int H, int W, int C, int ld, int OH, int OW, int stride,
                            mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || C <= 0 || stride <= 0) return MVIT_EINVAL;
   const long long M = (long long)B * OH * OW;
   hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((M + 63) / 64), (C + 63) / 64, 9), dim3(256), 0, (hipStream_t)stream,

@@ -2,6 +2,7 @@
 #include "gemm_kernel.hpp"
 
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   using namespace mvit_gemm;
   if (!args) return MVIT_EINVAL;
   const mvit_gemm_args& a = *args;

@@ -479,6 +479,7 @@ inline int nblk(long long work, int per, int cap) {
 extern "C" {
 
 MVIT_API int mvit_heads_moments(const void* x, double* mom, long long M, int nslots, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || nslots <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(moments_kernel, dim3(nblk(M, 64 * 8, 1024)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mom, M,
                      nslots);
@@ -489,6 +490,7 @@ MVIT_API int mvit_heads_bn_from_moments(const double* mom, const float* W1, cons
                                         const float* beta, float* running_mean, float* running_var, float* scale,
                                         float* shift, float* mean_out, float* rstd_out, double* mom_sum, int NH, int nslots,
                                         double count, float eps, float momentum, int training, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (NH <= 0 || NH > MAXH || (training && (!mom || nslots <= 0 || count <= 0))) return MVIT_EINVAL;
   hipLaunchKernelGGL(bn_from_moments_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mom, W1, b1, gamma, beta,
                      running_mean, running_var, scale, shift, mean_out, rstd_out, mom_sum, NH * HC, nslots, count, eps,
@@ -498,6 +500,7 @@ MVIT_API int mvit_heads_bn_from_moments(const double* mom, const float* W1, cons
 
 MVIT_API int mvit_heads_gate_fwd(const void* x, const float* W1, const float* b1, const float* scale, const float* shift,
                                  const float* W2, const float* b2, void* G, long long M, int NH, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
   hipLaunchKernelGGL(gate_fwd_kernel, dim3(nblk(M, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, W1, b1,
                      scale, shift, W2, b2, (bf16_t*)G, M, NH);
@@ -506,6 +509,7 @@ MVIT_API int mvit_heads_gate_fwd(const void* x, const float* W1, const float* b1
 
 MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, const float* b3, float* out, int B, int H,
                                  int W, int NH, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
   hipLaunchKernelGGL(conv_fwd_kernel, dim3(nblk((long long)B * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)G, W3, b3, out, B, H, W, NH);
@@ -514,6 +518,7 @@ MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, 
 
 MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x, const void* G, const float* W3, void* ET,
                                  float* dG, float* dXc, float* db3, int B, int H, int W, int NH, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
   hipLaunchKernelGGL(conv_bwd_kernel, dim3(nblk((long long)B * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dY, Y,
                      (const bf16_t*)x, (const bf16_t*)G, W3, (bf16_t*)ET, dG, dXc, db3, B, H, W, NH);
@@ -525,6 +530,7 @@ MVIT_API int mvit_heads_gate_bwd(const void* x, const void* G, const float* dG, 
                                  const float* rstd, const float* gamma, const float* W2, const double* mom_sum, double* red,
                                  float* coef, float* dW1, float* dgamma, float* dbeta, float* dW2, float* db2, void* dF,
                                  long long M, int NH, int nslots, double count, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || NH <= 0 || NH > MAXH || nslots <= 0) return MVIT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gate_bwd_reduce_kernel, dim3(nblk(M, GR_ROWS * 16, 2048)), dim3(256), 0, s, (const bf16_t*)x,

@@ -92,6 +92,7 @@ extern "C" {
 
 MVIT_API int mvit_wmse_fwd_bwd(const float* pred, const float* target, const float* w, double* loss_acc, float* dY, int B,
                                int C, long long HW, float lambda_factor, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || C <= 0 || HW <= 0) return MVIT_EINVAL;
   // loss = lambda/(C*B*HW) * sum_c w_c sum (p-t)^2  (caller scales loss_acc); dY = 2*lambda/(C*B*HW) * w_c * (p-t)
   const float coef = 2.f * lambda_factor / ((float)C * (float)B * (float)HW);
@@ -101,6 +102,7 @@ MVIT_API int mvit_wmse_fwd_bwd(const float* pred, const float* target, const flo
 }
 
 MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (n <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk(n, 1024 * 4, 1024)), dim3(256), 0, (hipStream_t)stream, x, out, n);
   return MVIT_LAUNCH_CHECK();
@@ -109,6 +111,7 @@ MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t
 MVIT_API int mvit_adam_clip_step(float* p, const float* g, float* m, float* v, const double* sqnorm, long long n, float lr,
                                  float beta1, float beta2, float eps, float bias_c1, float bias_c2, float max_norm,
                                  mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (n <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sqnorm, n, lr,
                      beta1, beta2, eps, bias_c1, bias_c2, max_norm);

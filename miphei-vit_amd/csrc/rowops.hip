@@ -255,6 +255,7 @@ extern "C" {
 
 MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, void* out, int M, int D, float eps,
                                 mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)out, M, D, eps);
   return MVIT_LAUNCH_CHECK();
@@ -262,6 +263,7 @@ MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, 
 
 MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, float* dx, const float* gamma_next,
                                 void* dy, int M, int D, float eps, int accumulate, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
   if ((dy != nullptr) != (gamma_next != nullptr)) return MVIT_EINVAL;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, x, w, dx,
@@ -271,6 +273,7 @@ MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, 
 
 MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int wsr, void* out, int ldo, int M, int K,
                             int R, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7)) return MVIT_EINVAL;
   hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, W, wsk,
                      wsr, (bf16_t*)out, ldo, M, K, R);
@@ -279,6 +282,7 @@ MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int
 
 MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, int osr, int osn, int M, int N,
                              int R, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || N <= 0 || R <= 0 || R > 16) return MVIT_EINVAL;
   hipLaunchKernelGGL(skinny_xty_kernel, dim3((N + 255) / 256, (M + XTY_ROWS - 1) / XTY_ROWS), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, out, osr, osn, M, N, R);
@@ -286,6 +290,7 @@ MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, flo
 }
 
 MVIT_API int mvit_im2col_patch(const float* img, void* out, int B, int S, int p, int g, int Kp, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || g <= 0 || g * p > S || Kp < 3 * p * p || (Kp & 7)) return MVIT_EINVAL;
   hipLaunchKernelGGL(im2col_patch_kernel, dim3(nblocks((long long)B * g * g * Kp, 256)), dim3(256), 0, (hipStream_t)stream,
                      img, (bf16_t*)out, B, S, p, g, Kp);
@@ -294,6 +299,7 @@ MVIT_API int mvit_im2col_patch(const float* img, void* out, int B, int S, int p,
 
 MVIT_API int mvit_prefix_tokens(float* x, const float* cls, const float* reg, int B, int ntok, int D, int R,
                                 mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (B <= 0 || D <= 0 || R < 0 || ntok < 1 + R) return MVIT_EINVAL;
   hipLaunchKernelGGL(prefix_tokens_kernel, dim3(nblocks((long long)B * (1 + R) * D, 256)), dim3(256), 0,
                      (hipStream_t)stream, x, cls, reg, B, ntok, D, R);
@@ -301,12 +307,14 @@ MVIT_API int mvit_prefix_tokens(float* x, const float* cls, const float* reg, in
 }
 
 MVIT_API int mvit_cast_f32_bf16(const float* src, void* dst, long long n, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (n <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(cast_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
   return MVIT_LAUNCH_CHECK();
 }
 
 MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out, int M, int D, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3)) return MVIT_EINVAL;
   hipLaunchKernelGGL(scale_cols_cast_kernel, dim3(nblocks((long long)M * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      gamma, (bf16_t*)out, M, D);
