@@ -80,9 +80,10 @@ MVIT_API int mvit_layernorm_bwd(const void* dh_bf16, const float* x, const float
  * LoRALayer.forward x @ A (src/generators/lora.py:16-18) and its adjoint dq @ B^T. */
 MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int wsr, void* out, int ldo, int M, int K,
                             int R, mvit_stream_t stream);
-/* out(f32)[r*osr + n*osn] += sum_m X(bf16)[m,r] * Y(bf16)[m,n], R <= 16 (LoRA weight gradients dA, dB). */
-MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, int osr, int osn, int M, int N,
-                             int R, mvit_stream_t stream);
+/* out(f32)[(r/rgrp)*osb + (r%rgrp)*osr + n*osn] += sum_m X(bf16)[m,r] * Y(bf16)[m,n], R <= 16
+ * (LoRA weight gradients dA = h^T dt, dB = t^T dq; rgrp/osb let one pass over Y fill the q and the v adapter). */
+MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, long long osb, int rgrp, int osr,
+                             int osn, int M, int N, int R, mvit_stream_t stream);
 /* NCHW f32 image -> bf16 patch matrix [B*g*g, Kp], k = c*p*p + iy*p + ix (timm PatchEmbed conv k=s=p). */
 MVIT_API int mvit_im2col_patch(const float* img, void* out_bf16, int B, int S, int p, int g, int Kp, mvit_stream_t stream);
 /* x[b,0]=cls, x[b,1..R]=reg  (timm _pos_embed with no_embed_class=True). */

@@ -163,30 +163,67 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------ out[r,n] += sum_m X[m,r] * Y[m,n], R <= 16
+// HBM-bound on Y: each lane owns 4 consecutive columns (8-byte loads), the 4 waves of a block split the rows of a
+// 128-row chunk, X rows are broadcast from LDS; partial sums meet in LDS, then one f32 atomic per output.
+// Output element (r, n) lives at out[(r / rgrp) * osb + (r % rgrp) * osr + n * osn]  (two LoRA matrices in one pass).
 constexpr int XTY_ROWS = 128;
 __global__ __launch_bounds__(256) void skinny_xty_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y,
-                                                         int ldy, float* __restrict__ out, int osr, int osn, int M, int N,
-                                                         int R) {
-  __shared__ float xs[XTY_ROWS][16];
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  const int mbeg = blockIdx.y * XTY_ROWS, mend = min(M, mbeg + XTY_ROWS);
+                                                         int ldy, float* __restrict__ out, long long osb, int rgrp, int osr,
+                                                         int osn, int M, int N, int R) {
+  __shared__ __attribute__((aligned(16))) float xs[XTY_ROWS][16];
+  __shared__ float red[4][16][256 + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 256 + lane * 4;
+  const int mbeg = blockIdx.y * XTY_ROWS;
   for (int i = threadIdx.x; i < XTY_ROWS * 16; i += 256) {
     const int m = mbeg + (i >> 4), r = i & 15;
     xs[i >> 4][r] = (m < M && r < R) ? bf2f(X[(size_t)m * ldx + r]) : 0.f;
   }
   __syncthreads();
-  if (n >= N) return;
-  float acc[16];
+  float acc[16][4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int m = mbeg; m < mend; ++m) {
-    const float y = bf2f(Y[(size_t)m * ldy + n]);
+  for (int r = 0; r < 16; ++r)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += xs[m - mbeg][r] * y;
+    for (int q = 0; q < 4; ++q) acc[r][q] = 0.f;
+  const bool full = n0 + 3 < N;
+  if (n0 < N) {
+#pragma unroll 4
+    for (int i = wave; i < XTY_ROWS; i += 4) {
+      const int m = mbeg + i;
+      if (m >= M) break;
+      float y[4];
+      if (full) {
+        const uint2 t = *(const uint2*)(Y + (size_t)m * ldy + n0);
+        y[0] = __uint_as_float(t.x << 16), y[1] = __uint_as_float(t.x & 0xffff0000u);
+        y[2] = __uint_as_float(t.y << 16), y[3] = __uint_as_float(t.y & 0xffff0000u);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = n0 + q < N ? bf2f(Y[(size_t)m * ldy + n0 + q]) : 0.f;
+      }
+      const float4* xr = (const float4*)xs[i];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 xv = xr[r4];
+        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[r4 * 4 + k][q] += xx[k] * y[q];
+      }
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r)
-    if (r < R) atomicAdd(out + (size_t)r * osr + (size_t)n * osn, acc[r]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[wave][r][lane * 4 + q] = acc[r][q];
+  __syncthreads();
+  for (int e = threadIdx.x; e < R * 256; e += 256) {
+    const int r = e >> 8, c = e & 255, n = blockIdx.x * 256 + c;
+    if (n < N) {
+      const float v = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+      atomicAdd(out + (size_t)(r / rgrp) * osb + (size_t)(r % rgrp) * osr + (size_t)n * osn, v);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ patch gather: NCHW f32 image -> [B*g*g, Kp] bf16
@@ -280,12 +317,12 @@ MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int
   return MVIT_LAUNCH_CHECK();
 }
 
-MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, int osr, int osn, int M, int N,
-                             int R, mvit_stream_t stream) {
+MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, long long osb, int rgrp, int osr,
+                             int osn, int M, int N, int R, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || N <= 0 || R <= 0 || R > 16) return MVIT_EINVAL;
+  if (M <= 0 || N <= 0 || R <= 0 || R > 16 || rgrp <= 0 || (ldy & 3)) return MVIT_EINVAL;
   hipLaunchKernelGGL(skinny_xty_kernel, dim3((N + 255) / 256, (M + XTY_ROWS - 1) / XTY_ROWS), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, out, osr, osn, M, N, R);
+                     (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, out, osb, rgrp, osr, osn, M, N, R);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -268,9 +268,10 @@ class HipEngine:
             B2[:, :D, :r] = (c.alpha * Bq).transpose(1, 2)
             B2[:, 2 * D:, r:] = (c.alpha * Bv).transpose(1, 2)
             pk.B2 = B2                                                              # [L, 3D, 2r] bf16
+            pk.AcatT = pk.Acat.transpose(1, 2).to(bf).contiguous()                 # [L, 2r, D]: B operand of t = h @ A
             if need_bwd:
                 pk.Acat16 = pk.Acat.to(bf)                                          # B2 operand of the dh1 GEMM
-                pk.Bq, pk.Bv = (c.alpha * Bq).contiguous(), (c.alpha * Bv).contiguous()
+                pk.B2T = B2.transpose(1, 2).contiguous()                            # [L, 2r, 3D]: B operand of dt = dqkv @ B^T
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
         for i, cv in enumerate(convs):
@@ -326,7 +327,7 @@ class HipEngine:
         w.x_mid = [e(M, D, dt=torch.float32) for _ in range(nl)]
         w.h1 = [e(M, D) for _ in range(nl)]
         w.h2 = e(M, D)
-        w.t = [e(M, 16) for _ in range(nl)] if c.lora else None
+        w.t = [e(M, 2 * c.rank) for _ in range(nl)] if c.lora else None
         w.qkv = [e(M, 3 * D) for _ in range(nl)]
         w.o = [e(M, D) for _ in range(nl)]
         w.lse = [e(B, c.H, c.ntok, dt=torch.float32) for _ in range(nl)]
@@ -402,7 +403,7 @@ class HipEngine:
             w.do = e(M, D)
             w.dqkv = e(M, 3 * D)
             w.dsum = e(B, c.H, c.ntok, dt=torch.float32)
-            w.dt = e(M, 16) if c.lora else None
+            w.dt = e(M, 2 * c.rank) if c.lora else None
         self._ws[key] = w
         return w
 
@@ -424,7 +425,7 @@ class HipEngine:
             xout = w.x_in[l + 1] if train else w.x_in[0]
             ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
             if c.lora:
-                ops.skinny_xw(w.h1[i], pk.Acat[l], w.t[i], R=2 * c.rank)
+                ops.gemm(w.h1[i], pk.AcatT[l], w.t[i])
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv, a2=w.t[i], b2=pk.B2[l], K2=2 * c.rank)
             else:
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
@@ -665,13 +666,13 @@ class HipEngine:
             ops.gemm(w.dy, b.t.wproj, w.do)
             ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, w.dqkv, B, c.ntok, c.H, c.Dh, scale)
             dq, dv = w.dqkv, w.dqkv.view(-1)[2 * D:]
-            ops.skinny_xw(dq, pk.Bq[l], w.dt, ldx=3 * D, wsk=1, wsr=D, ldo=16, M=M, K=D, R=r_)
-            ops.skinny_xw(dv, pk.Bv[l], w.dt.view(-1)[r_:], ldx=3 * D, wsk=1, wsr=D, ldo=16, M=M, K=D, R=r_)
+            ops.gemm(w.dqkv, pk.B2T[l], w.dt)                       # dt = [dq @ (aB_q)^T | dv @ (aB_v)^T]
             t = w.t[l]
-            ops.skinny_xty(t, dq, fl.dBq[l], ldx=16, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
-            ops.skinny_xty(t.view(-1)[r_:], dv, fl.dBv[l], ldx=16, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
-            ops.skinny_xty(w.dt, w.h1[l], fl.dAq[l], ldx=16, ldy=D, osr=1, osn=r_, M=M, N=D, R=r_)
-            ops.skinny_xty(w.dt.view(-1)[r_:], w.h1[l], fl.dAv[l], ldx=16, ldy=D, osr=1, osn=r_, M=M, N=D, R=r_)
+            ops.skinny_xty(t, dq, fl.dBq[l], ldx=2 * r_, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
+            ops.skinny_xty(t.view(-1)[r_:], dv, fl.dBv[l], ldx=2 * r_, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
+            # dA_q | dA_v in one pass over h1: rows 0..r-1 -> lora_q.A^T, rows r..2r-1 -> lora_v.A^T
+            ops.skinny_xty(w.dt, w.h1[l], fl.dAq[l], ldx=2 * r_, ldy=D, osb=fl.dAv[l].data_ptr() // 4 - fl.dAq[l].data_ptr() // 4,
+                           rgrp=r_, osr=1, osn=r_, M=M, N=D, R=2 * r_)
             if l > 0:
                 ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
                 ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)

@@ -117,10 +117,11 @@ def skinny_xw(X, W, out, *, ldx=None, wsk=None, wsr=None, ldo=None, M=None, K=No
     return out
 
 
-def skinny_xty(X, Y, out, *, ldx=None, ldy=None, osr=None, osn=None, M=None, N=None, R=None):
-    _call("mvit_skinny_xty", _p(X), ldx or X.stride(0), _p(Y), ldy or Y.stride(0), _p(out),
+def skinny_xty(X, Y, out, *, ldx=None, ldy=None, osr=None, osn=None, M=None, N=None, R=None, osb=0, rgrp=None):
+    R = R or X.shape[1]
+    _call("mvit_skinny_xty", _p(X), ldx or X.stride(0), _p(Y), ldy or Y.stride(0), _p(out), osb, rgrp or R,
           osr if osr is not None else out.stride(0), osn if osn is not None else out.stride(1), M or X.shape[0],
-          N or Y.shape[1], R or X.shape[1])
+          N or Y.shape[1], R)
     return out
 
 

@@ -67,6 +67,14 @@ def test_skinny():
     accT = torch.zeros(200, 8, device="cuda")
     ops.skinny_xty(T, Y, accT, osr=1, osn=8, R=8)
     assert _rel(accT, Y.float().t() @ T[:, :8].float()) < 1e-5
+    # both halves in one pass, each to its own [200, 8] matrix
+    two = torch.zeros(2, 200, 8, device="cuda")
+    ops.skinny_xty(T, Y, two, osb=200 * 8, rgrp=8, osr=1, osn=8, R=16)
+    assert _rel(two[0], Y.float().t() @ T[:, :8].float()) < 1e-5 and _rel(two[1], Y.float().t() @ T[:, 8:].float()) < 1e-5
+    Y2 = torch.randn(M, 1000, device="cuda").bfloat16()[:, :998]
+    acc2 = torch.zeros(16, 998, device="cuda")
+    ops.skinny_xty(T, Y2, acc2, ldy=1000, R=16)
+    assert _rel(acc2, T.float().t() @ Y2.float()) < 1e-5
 
 
 def test_patch_prefix_cast():
