@@ -82,24 +82,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
     }
   }
 
-  uint4 ra[A_CH], rb[B_CH];
+  // ---- operand staging: global -> LDS directly (buffer_load ... lds, 16 B per lane, no VGPR round trip).
+  // One wave instruction fills 8 consecutive 128-byte LDS rows (lane l -> row l>>3, 16-byte slot l&7); the XOR
+  // swizzle lives on the SOURCE side: slot s of row r receives global chunk s ^ ((r>>1)&7).  Out-of-range rows,
+  // the K tail and the zero padding of the convolution window use an out-of-bounds offset (hardware returns 0).
+  constexpr unsigned OOB = 0x80000000u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int c8s = c8 ^ ((row_base >> 1) & 7);  // source chunk for this lane's LDS slot (same for every +32 row)
+  const bf16_t* a_base = (AMODE == MVIT_A_DENSE) ? Ap + (size_t)m0 * p.lda : Ap;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(Bp + (size_t)n0 * p.ldb), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(A2p ? A2p + (size_t)m0 * p.lda2 : Ap), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(B2p ? B2p + (size_t)n0 * p.ldb2 : Bp), 0, 0x7fffffff, 0x00020000);
 
-  auto load_tile = [&](int t) {
+  auto issue_tile = [&](int t, int buf) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
+    char* b = a + A_BYTES;
     const bool ext = t >= nk1;
-    const int k0 = (ext ? t - nk1 : t) * BK + c8 * 8;
+    const int k0 = (ext ? t - nk1 : t) * BK + c8s * 8;
     const int klim = ext ? p.K2 : p.K;
     const bool kok = k0 < klim;
-    // ---- A
     if (AMODE == MVIT_A_DENSE || ext) {
-      const bf16_t* src = ext ? A2p : Ap;
       const int ld = ext ? p.lda2 : p.lda;
 #pragma unroll
       for (int j = 0; j < A_CH; ++j) {
-        const int gm = m0 + row_base + 32 * j;
-        if (kok && gm < p.M)
-          ra[j] = *(const uint4*)(src + (size_t)gm * ld + k0);
+        const int r = row_base + 32 * j;
+        const unsigned off = (kok && m0 + r < p.M) ? (unsigned)(((size_t)r * ld + k0) * 2) : OOB;
+        if (ext)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
         else
-          ra[j] = make_uint4(0, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
       }
     } else {
       const int tap = k0 / p.conv_C, ch = k0 - tap * p.conv_C;
@@ -119,39 +134,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
           ok = ok && (iy * p.conv_stride == ty) && (ix * p.conv_stride == tx);
         }
         ok = ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W;
-        if (ok)
-          ra[j] = *(const uint4*)(Ap + ((size_t)(crow[j].b * p.conv_H + iy) * p.conv_W + ix) * p.conv_ld + ch);
-        else
-          ra[j] = make_uint4(0, 0, 0, 0);
+        const unsigned off =
+            ok ? (unsigned)((((size_t)(crow[j].b * p.conv_H + iy) * p.conv_W + ix) * p.conv_ld + ch) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
       }
     }
-    // ---- B
     {
-      const bf16_t* src = ext ? B2p : Bp;
       const int ld = ext ? p.ldb2 : p.ldb;
 #pragma unroll
       for (int j = 0; j < B_CH; ++j) {
-        const int gn = n0 + row_base + 32 * j;
-        if (kok && gn < p.N)
-          rb[j] = *(const uint4*)(src + (size_t)gn * ld + k0);
+        const int r = row_base + 32 * j;
+        const unsigned off = (kok && n0 + r < p.N) ? (unsigned)(((size_t)r * ld + k0) * 2) : OOB;
+        if (ext)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * 32 * 128), 16, off, 0, 0, 0);
         else
-          rb[j] = make_uint4(0, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * 32 * 128), 16, off, 0, 0, 0);
       }
-    }
-  };
-
-  auto store_tile = [&](int buf) {
-    char* a = smem + buf * BUF_BYTES;
-    char* b = a + A_BYTES;
-#pragma unroll
-    for (int j = 0; j < A_CH; ++j) {
-      const int row = row_base + 32 * j;
-      *(uint4*)(a + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < B_CH; ++j) {
-      const int row = row_base + 32 * j;
-      *(uint4*)(b + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = rb[j];
     }
   };
 
@@ -165,13 +163,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
 
   const int frag_row = lane & 31, frag_half = lane >> 5;
 
-  load_tile(t_begin);
-  store_tile(0);
+  issue_tile(t_begin, 0);
   __syncthreads();
   int cur = 0;
   for (int t = t_begin; t < t_end; ++t) {
-    const bool more = t + 1 < t_end;
-    if (more) load_tile(t + 1);
+    if (t + 1 < t_end) issue_tile(t + 1, cur ^ 1);  // lands while the MFMAs below run; drained before the barrier
     const char* a = smem + cur * BUF_BYTES;
     const char* b = a + A_BYTES;
 #pragma unroll
@@ -194,7 +190,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
