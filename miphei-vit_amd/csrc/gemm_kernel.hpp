@@ -11,6 +11,7 @@
 // convolution, forward and adjoint), so the decoder convolutions run on the same mainloop.
 // Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/miphei_hip.h"
 
@@ -89,29 +90,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
   constexpr unsigned OOB = 0x80000000u;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int c8s = c8 ^ ((row_base >> 1) & 7);  // source chunk for this lane's LDS slot (same for every +32 row)
-  const bf16_t* a_base = (AMODE == MVIT_A_DENSE) ? Ap + (size_t)m0 * p.lda : Ap;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(Bp + (size_t)n0 * p.ldb), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(A2p ? A2p + (size_t)m0 * p.lda2 : Ap), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(B2p ? B2p + (size_t)n0 * p.ldb2 : Bp), 0, 0x7fffffff, 0x00020000);
+  auto make_rsrc = [](const bf16_t* ptr) {
+    // wave-uniform by construction (kernel arguments + blockIdx arithmetic); readfirstlane makes it provable so the
+    // descriptor stays in SGPRs and hipcc does not wrap every buffer_load in a waterfall loop
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc((AMODE == MVIT_A_DENSE) ? Ap + (size_t)m0 * p.lda : Ap);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(Bp + (size_t)n0 * p.ldb);
+  const __amdgpu_buffer_rsrc_t rsA2 = make_rsrc(A2p ? A2p + (size_t)m0 * p.lda2 : Ap);
+  const __amdgpu_buffer_rsrc_t rsB2 = make_rsrc(B2p ? B2p + (size_t)n0 * p.ldb2 : Bp);
 
-  auto issue_tile = [&](int t, int buf) {
+  auto issue_tile_impl = [&](int t, int buf, auto ext_tag) {
+    constexpr bool ext = decltype(ext_tag)::value;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
     char* b = a + A_BYTES;
-    const bool ext = t >= nk1;
     const int k0 = (ext ? t - nk1 : t) * BK + c8s * 8;
     const int klim = ext ? p.K2 : p.K;
     const bool kok = k0 < klim;
-    if (AMODE == MVIT_A_DENSE || ext) {
+    if constexpr (AMODE == MVIT_A_DENSE || ext) {
       const int ld = ext ? p.lda2 : p.lda;
 #pragma unroll
       for (int j = 0; j < A_CH; ++j) {
         const int r = row_base + 32 * j;
-        const unsigned off = (kok && m0 + r < p.M) ? (unsigned)(((size_t)r * ld + k0) * 2) : OOB;
-        if (ext)
+        const unsigned lin = ((unsigned)r * (unsigned)ld + (unsigned)k0) * 2u;
+        const unsigned off = (kok && m0 + r < p.M) ? lin : OOB;
+        if constexpr (ext)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
         else
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
@@ -134,8 +140,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
           ok = ok && (iy * p.conv_stride == ty) && (ix * p.conv_stride == tx);
         }
         ok = ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W;
-        const unsigned off =
-            ok ? (unsigned)((((size_t)(crow[j].b * p.conv_H + iy) * p.conv_W + ix) * p.conv_ld + ch) * 2) : OOB;
+        const unsigned lin =
+            (((unsigned)(crow[j].b * p.conv_H + iy) * (unsigned)p.conv_W + (unsigned)ix) * (unsigned)p.conv_ld + (unsigned)ch) * 2u;
+        const unsigned off = ok ? lin : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
       }
     }
@@ -144,13 +151,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
 #pragma unroll
       for (int j = 0; j < B_CH; ++j) {
         const int r = row_base + 32 * j;
-        const unsigned off = (kok && n0 + r < p.N) ? (unsigned)(((size_t)r * ld + k0) * 2) : OOB;
-        if (ext)
+        const unsigned lin = ((unsigned)r * (unsigned)ld + (unsigned)k0) * 2u;
+        const unsigned off = (kok && n0 + r < p.N) ? lin : OOB;
+        if constexpr (ext)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * 32 * 128), 16, off, 0, 0, 0);
         else
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * 32 * 128), 16, off, 0, 0, 0);
       }
     }
+  };
+
+  auto issue_tile = [&](int t, int buf) {
+    if (t < nk1)
+      issue_tile_impl(t, buf, std::false_type{});
+    else
+      issue_tile_impl(t, buf, std::true_type{});
   };
 
   f32x16 acc[TM][TN];
