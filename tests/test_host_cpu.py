@@ -1,0 +1,135 @@
+"""CPU: host logic, C-ABI surface, data-parallel exchange (gloo, world_size 2).  No GPU compute here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every MVIT_API function of include/miphei_hip.h is exported by the built library and bound by ctypes."""
+    import __graft_entry__ as g
+    from miphei_vit_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    hdr = open(os.path.join(ROOT, "include", "miphei_hip.h")).read()
+    declared = set(re.findall(r"MVIT_API\s+int\s+(mvit_\w+)\s*\(", hdr))
+    assert len(declared) >= 28
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    _lib.lib()
+    # struct layout of mvit_gemm_args matches the C definition (pointers first, then ints, 8-byte aligned)
+    body = hdr[hdr.index("typedef struct mvit_gemm_args"):hdr.index("} mvit_gemm_args;")]
+    n_ptr = len(re.findall(r"\*\s*\w+\s*[;,]", body))
+    n_int = sum(len(l.replace("int", "", 1).split(",")) for l in body.splitlines() if l.strip().startswith("int "))
+    assert (n_ptr, n_int) == (10, 25)
+    assert ctypes.sizeof(_lib.GemmArgs) == n_ptr * 8 + ((n_int * 4 + 7) // 8) * 8
+
+
+def test_state_dict_contract_and_flat_freeze():
+    from oracle import VIT_CONFIGS
+    from oracle.model import generator_state_shapes
+    from miphei_vit_amd.generators import get_generator, get_vitmatte
+    m = get_vitmatte("tiny_swiglu", 128, 16, use_lora=True, pretrained=False)
+    sd = m.state_dict()
+    shapes = generator_state_shapes(VIT_CONFIGS["tiny_swiglu"], 128, 16)
+    assert sorted(sd) == sorted(shapes)
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    train = {k for k, p in m.named_parameters() if p.requires_grad}
+    assert all((".lora_" in k) or k.startswith("decoder.") for k in train)
+    assert not any(p.requires_grad for k, p in m.named_parameters() if k.startswith("encoder.") and ".lora_" not in k)
+    assert hasattr(m, "encoder") and hasattr(m.encoder, "vit") and m.encoder.num_prefix_tokens == 5
+    assert m.encoder.grid_size == (9, 9) and m.encoder.embed_dim == 96
+    assert abs(m.encoder.scale_factor[0] - 8 / 9) < 1e-12
+    cfg = {"model": {"model_name": "myvitmatte", "encoder": {"encoder_name": "tiny", "encoder_weights": None,
+                                                             "pretrained": False}}}
+    g = get_generator("myvitmatte", 128, 3, 3, cfg)
+    assert type(g).__name__ == "ViTMatte"
+    with pytest.raises(NotImplementedError):
+        get_generator("smp_unet", 128, 3, 3, cfg)
+    with pytest.raises(ValueError):
+        m.set_input_size((100, 100))
+    with pytest.raises(ValueError):
+        m.set_input_size((64, 64))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 128, 128))  # no CPU fallback: the product path fails loudly without a ROCm device
+
+
+def test_hoptimus0_key_contract_on_meta_device(golden_dir):
+    from miphei_vit_amd.generators import get_vitmatte
+    g = np.load(os.path.join(golden_dir, "keys_f256.npz"))
+    with torch.device("meta"):
+        m = get_vitmatte("hoptimus0", 256, 16, use_lora=True, pretrained=False)
+    assert sorted(m.state_dict().keys()) == list(g["keys"]) and len(m.state_dict()) == 945
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert n_train == 6697712
+    assert sum(p.numel() for p in m.parameters()) == 1141576432
+
+
+def test_lr_schedule_loss_and_resample_tables():
+    import torch.nn.functional as F
+    from miphei_vit_amd.loss import WeightedMSELoss, marker_weights_from_stats
+    from miphei_vit_amd.resample import _DENSE
+    from miphei_vit_amd.utils import pix2pix_lr_scheduler
+    from oracle import weighted_mse_loss
+    f = pix2pix_lr_scheduler(1000, 400, 500)
+    assert [f(0), f(200), f(450), f(750), f(1000)] == [0.0, 0.5, 1.0, 0.5, 0.0]
+    w = marker_weights_from_stats([2.0, 1.0, 4.0])
+    assert torch.allclose(w, torch.tensor([2.0, 4.0, 1.0]))
+    y, p = torch.randn(2, 3, 8, 8), torch.randn(2, 3, 8, 8)
+    assert torch.allclose(WeightedMSELoss(50.0, w)(y, p), weighted_mse_loss(y, p, w, 50.0))
+    for mode, (i, o) in [("bilinear", (16, 32)), ("bicubic", (18, 16)), ("bicubic", (36, 32))]:
+        R = torch.from_numpy(_DENSE[mode](i, o))
+        x = torch.randn(1, 1, i, i, dtype=torch.float64)
+        ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) if mode == "bilinear" else \
+            F.interpolate(x, scale_factor=(o / i, o / i), mode="bicubic")
+        assert float((R @ x[0, 0] @ R.T - ref[0, 0]).abs().max()) < 1e-12
+
+
+def test_swiglu_pack_index_is_a_permutation():
+    from miphei_vit_amd.engine import swiglu_pack_index
+    for hidden in (512, 8192):
+        idx = swiglu_pack_index(hidden)
+        assert sorted(idx.tolist()) == list(range(hidden))
+        H = hidden // 2
+        assert idx[0] == 0 and idx[32] == H and idx[64] == 32 and idx[96] == H + 32
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from miphei_vit_amd.trainer import allreduce_mean_
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+g = torch.Generator().manual_seed(7)
+full = torch.randn(world, 1000, generator=g)          # per-rank gradients of a sharded minibatch
+mine = full[rank].clone()
+allreduce_mean_(mine, world)
+assert torch.allclose(mine, full.mean(0), atol=1e-6), "all-reduce mean mismatch"
+# sharding a minibatch: every rank gets a disjoint, equal slice of the global tile indices
+B = 8
+idx = torch.arange(B * world)[rank * B:(rank + 1) * B]
+gathered = [torch.empty_like(idx) for _ in range(world)]
+dist.all_gather(gathered, idx)
+assert torch.equal(torch.cat(gathered), torch.arange(B * world))
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_gloo_world2_gradient_exchange(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
