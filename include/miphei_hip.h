@@ -76,10 +76,10 @@ MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, 
  * dy(bf16) = gamma_next * dx_total (the LayerScale-scaled gradient of the preceding residual branch). */
 MVIT_API int mvit_layernorm_bwd(const void* dh_bf16, const float* x, const float* w, float* dx, const float* gamma_next,
                                 void* dy_bf16, int M, int D, float eps, int accumulate, mvit_stream_t stream);
-/* out(bf16)[M,R] = X(bf16)[M,K] @ W(f32)[K,R], R <= 16, W element (k,r) at W[k*wsk + r*wsr].
+/* out(bf16)[M,R] = X(bf16)[M,K] @ W(bf16)[R,K]^T, R <= 16 (one wave per 16 rows on the 16x16x32 MFMA).
  * LoRALayer.forward x @ A (src/generators/lora.py:16-18) and its adjoint dq @ B^T. */
-MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int wsr, void* out, int ldo, int M, int K,
-                            int R, mvit_stream_t stream);
+MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void* out, int ldo, int M, int K, int R,
+                            mvit_stream_t stream);
 /* out(f32)[(r/rgrp)*osb + (r%rgrp)*osr + n*osn] += sum_m X(bf16)[m,r] * Y(bf16)[m,n], R <= 16
  * (LoRA weight gradients dA = h^T dt, dB = t^T dq; rgrp/osb let one pass over Y fill the q and the v adapter). */
 MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, long long osb, int rgrp, int osr,

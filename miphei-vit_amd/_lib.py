@@ -37,7 +37,7 @@ SIGNATURES = {
     "mvit_gemm_bf16": [C.POINTER(GemmArgs), vp],
     "mvit_layernorm_fwd": [vp, vp, vp, vp, ci, ci, cf, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
-    "mvit_skinny_xw": [vp, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp],
+    "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
     "mvit_skinny_xty": [vp, ci, vp, ci, vp, ll, ci, ci, ci, ci, ci, ci, vp],
     "mvit_im2col_patch": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_prefix_tokens": [vp, vp, vp, ci, ci, ci, ci, vp],

@@ -129,36 +129,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// ------------------------------------------------------------------ out[M,R] = X[M,K] @ W[K,R], R <= 16
-__global__ __launch_bounds__(256) void skinny_xw_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ W,
-                                                        int wsk, int wsr, bf16_t* __restrict__ out, int ldo, int M, int K,
-                                                        int R) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  float acc[16];
+// ------------------------------------------------------------------ out[M,R] = X[M,K] @ W[R,K]^T, R <= 16
+// LoRA down-projection (x @ A) and its adjoint (dq @ B^T): M is large, R tiny.  One wavefront per 16 rows on
+// v_mfma_f32_16x16x32_bf16 (N = 16 exactly), fragments loaded straight from global memory (X is streamed once,
+// W is L2-resident), 8 k-steps of loads in flight per wave.
+__global__ __launch_bounds__(64) void skinny_xw_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
+                                                       int ldw, bf16_t* __restrict__ out, int ldo, int M, int K, int R) {
+  const int lane = threadIdx.x, r16 = lane & 15, kq = lane >> 4;
+  const int row = blockIdx.x * 16 + r16;
+  const bool rok = row < M, wok = r16 < R;
+  const bf16_t* xp = X + (size_t)(rok ? row : 0) * ldx + kq * 8;
+  const bf16_t* wp = W + (size_t)(wok ? r16 : 0) * ldw + kq * 8;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  int k = 0;
+  for (; k + 256 <= K; k += 256) {
+    uint4 xa[8], wb[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const bf16_t* xr = X + (size_t)row * ldx;
-  for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    const uint4 t = *(const uint4*)(xr + k0);
-    const uint32_t u[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xv = (j & 1) ? __uint_as_float(u[j >> 1] & 0xffff0000u) : __uint_as_float(u[j >> 1] << 16);
-      const float* wr = W + (size_t)(k0 + j) * wsk;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (r < R) acc[r] += xv * wr[(size_t)r * wsr];
+    for (int u = 0; u < 8; ++u) {
+      xa[u] = rok ? *(const uint4*)(xp + k + 32 * u) : zero;
+      wb[u] = wok ? *(const uint4*)(wp + k + 32 * u) : zero;
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&xa[u], *(bf16x8*)&wb[u], acc, 0, 0, 0);
   }
+  for (; k < K; k += 32) {
+    const bool kok = k + kq * 8 < K;
+    const uint4 xa = (rok && kok) ? *(const uint4*)(xp + k) : zero;
+    const uint4 wb = (wok && kok) ? *(const uint4*)(wp + k) : zero;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&xa, *(const bf16x8*)&wb, acc, 0, 0, 0);
+  }
+  // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  if (r16 < R) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = wave_sum(acc[r]);
-  if (lane < R) {
-    float v = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (lane == r) v = acc[r];
-    out[(size_t)row * ldo + lane] = f2bf(v);
+    for (int j = 0; j < 4; ++j) {
+      const int orow = blockIdx.x * 16 + kq * 4 + j;
+      if (orow < M) out[(size_t)orow * ldo + r16] = f2bf(acc[j]);
+    }
   }
 }
 
@@ -308,12 +316,12 @@ MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, 
   return MVIT_LAUNCH_CHECK();
 }
 
-MVIT_API int mvit_skinny_xw(const void* X, int ldx, const float* W, int wsk, int wsr, void* out, int ldo, int M, int K,
-                            int R, mvit_stream_t stream) {
+MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void* out, int ldo, int M, int K, int R,
+                            mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7)) return MVIT_EINVAL;
-  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, W, wsk,
-                     wsr, (bf16_t*)out, ldo, M, K, R);
+  if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7) || (ldw & 7)) return MVIT_EINVAL;
+  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
+                     (const bf16_t*)W, ldw, (bf16_t*)out, ldo, M, K, R);
   return MVIT_LAUNCH_CHECK();
 }
 

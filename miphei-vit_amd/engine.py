@@ -271,7 +271,7 @@ class HipEngine:
             pk.AcatT = pk.Acat.transpose(1, 2).to(bf).contiguous()                 # [L, 2r, D]: B operand of t = h @ A
             if need_bwd:
                 pk.Acat16 = pk.Acat.to(bf)                                          # B2 operand of the dh1 GEMM
-                pk.B2T = B2.transpose(1, 2).contiguous()                            # [L, 2r, 3D]: B operand of dt = dqkv @ B^T
+                pk.Bq16, pk.Bv16 = (c.alpha * Bq).to(bf).contiguous(), (c.alpha * Bv).to(bf).contiguous()  # [L, r, D]
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
         for i, cv in enumerate(convs):
@@ -425,7 +425,7 @@ class HipEngine:
             xout = w.x_in[l + 1] if train else w.x_in[0]
             ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
             if c.lora:
-                ops.gemm(w.h1[i], pk.AcatT[l], w.t[i])
+                ops.skinny_xw(w.h1[i], pk.AcatT[l], w.t[i])
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv, a2=w.t[i], b2=pk.B2[l], K2=2 * c.rank)
             else:
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
@@ -666,7 +666,8 @@ class HipEngine:
             ops.gemm(w.dy, b.t.wproj, w.do)
             ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, w.dqkv, B, c.ntok, c.H, c.Dh, scale)
             dq, dv = w.dqkv, w.dqkv.view(-1)[2 * D:]
-            ops.gemm(w.dqkv, pk.B2T[l], w.dt)                       # dt = [dq @ (aB_q)^T | dv @ (aB_v)^T]
+            ops.skinny_xw(dq, pk.Bq16[l], w.dt, ldx=3 * D, ldo=2 * r_, M=M)                    # dt_q = dq @ (a B_q)^T
+            ops.skinny_xw(dv, pk.Bv16[l], w.dt.view(-1)[r_:], ldx=3 * D, ldo=2 * r_, M=M)      # dt_v = dv @ (a B_v)^T
             t = w.t[l]
             ops.skinny_xty(t, dq, fl.dBq[l], ldx=2 * r_, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
             ops.skinny_xty(t.view(-1)[r_:], dv, fl.dBv[l], ldx=2 * r_, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)

@@ -110,10 +110,12 @@ def layernorm_bwd(dh, x, w, dx, gamma_next=None, dy=None, eps=1e-6, accumulate=T
     _call("mvit_layernorm_bwd", _p(dh), _p(x), _p(w), _p(dx), _p(gamma_next), _p(dy), M, D, eps, int(accumulate))
 
 
-def skinny_xw(X, W, out, *, ldx=None, wsk=None, wsr=None, ldo=None, M=None, K=None, R=None):
-    M = M or X.shape[0]
-    _call("mvit_skinny_xw", _p(X), ldx or X.stride(0), _p(W), wsk if wsk is not None else W.stride(0),
-          wsr if wsr is not None else W.stride(1), _p(out), ldo or out.stride(0), M, K or W.shape[0], R or W.shape[1])
+def skinny_xw(X, W, out, *, ldx=None, ldw=None, ldo=None, M=None, K=None, R=None):
+    """out[M,R] = X[M,K] @ W[R,K]^T (bf16 operands, R <= 16)."""
+    _chk_bf16(X, "X")
+    _chk_bf16(W, "W")
+    _call("mvit_skinny_xw", _p(X), ldx or X.stride(0), _p(W), ldw or W.stride(0), _p(out), ldo or out.stride(0),
+          M or X.shape[0], K or W.shape[1], R or W.shape[0])
     return out
 
 

@@ -49,15 +49,16 @@ def test_skinny():
     ops = _ops()
     M, K, R = 700, 1536, 16
     X = _rand(M, K, seed=1).bfloat16()
-    W = _rand(K, R, seed=2, scale=0.1)
+    W = _rand(R, K, seed=2, scale=0.1).bfloat16()
     out = torch.empty(M, R, device="cuda", dtype=torch.bfloat16)
     ops.skinny_xw(X, W, out)
-    assert _rel(out.float(), X.float() @ W) < 4e-3
-    # strided W (B^T with B [8, K]) writing into a column slice
-    Bm = _rand(8, K, seed=3, scale=0.1)
+    assert _rel(out.float(), X.float() @ W.float().t()) < 4e-3
+    # R = 8 into a column slice, X a column window of a wider matrix, ragged K
+    Xw = _rand(M, 3 * 104, seed=7).bfloat16()
+    Bm = _rand(8, 104, seed=3, scale=0.1).bfloat16()
     out2 = torch.zeros(M, 16, device="cuda", dtype=torch.bfloat16)
-    ops.skinny_xw(X, Bm, out2[:, 8:], wsk=1, wsr=K, ldo=16, K=K, R=8)
-    assert _rel(out2[:, 8:].float(), X.float() @ Bm.t()) < 4e-3 and float(out2[:, :8].abs().max()) == 0
+    ops.skinny_xw(Xw.view(-1)[2 * 104:], Bm, out2.view(-1)[8:], ldx=3 * 104, ldo=16, M=M)
+    assert _rel(out2[:, 8:].float(), Xw[:, 208:].float() @ Bm.float().t()) < 4e-3 and float(out2[:, :8].abs().max()) == 0
     # X^T Y
     T = _rand(M, 16, seed=4).bfloat16()
     Y = _rand(M, 200, seed=5).bfloat16()
