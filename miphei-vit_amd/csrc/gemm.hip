@@ -1,4 +1,5 @@
 // Dispatcher of the bf16 MFMA GEMM / implicit-GEMM convolution (kernel in gemm_kernel.hpp).
+#include <cstdlib>
 #include "gemm_kernel.hpp"
 
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
@@ -17,11 +18,16 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   if (a.epi == MVIT_EPI_PATCH && (!a.pos || a.patch_P <= 0)) return MVIT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool dense = a.amode == MVIT_A_DENSE;
+  static const int big_tile = [] { const char* e = getenv("MVIT_GEMM_BIG_TILE"); return e ? atoi(e) : 1; }();
+  const bool big = big_tile && a.M >= 1024;  // 8-wave 256x128 tile, 3-stage DMA pipeline
   if (a.epi == MVIT_EPI_SWIGLU) {
     if ((a.N % 128) || !dense) return MVIT_EINVAL;
-    return launch_dense<128, 128, 2, 2>(a, s);
+    return big ? launch_dense<256, 128, 4, 2>(a, s) : launch_dense<128, 128, 2, 2>(a, s);
   }
-  if (a.N % 128 == 0 || a.N >= 256) return dense ? launch_dense<128, 128, 2, 2>(a, s) : launch_conv<128, 128, 2, 2>(a, s);
+  if (a.N % 128 == 0 || a.N >= 256) {
+    if (big) return dense ? launch_dense<256, 128, 4, 2>(a, s) : launch_conv<256, 128, 4, 2>(a, s);
+    return dense ? launch_dense<128, 128, 2, 2>(a, s) : launch_conv<128, 128, 2, 2>(a, s);
+  }
   if (a.N > 32) return dense ? launch_dense<128, 64, 2, 2>(a, s) : launch_conv<128, 64, 2, 2>(a, s);
   return dense ? launch_dense<128, 32, 4, 1>(a, s) : launch_conv<128, 32, 4, 1>(a, s);
 }

@@ -24,13 +24,19 @@ struct ConvRow {
   bool ok;
 };
 
+// number of LDS stages: the 8-wave 256x128 tile runs one block per CU and keeps two K tiles of DMA in flight
+constexpr int gemm_stages(int bm, int bn) { return (bm + bn) * 128 * 3 <= 160 * 1024 && bm >= 256 ? 3 : 2; }
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit_gemm_args p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;  // threads
+  constexpr int RPI = NT / 8;                 // tile rows filled per DMA instruction of the block
+  constexpr int NSTAGE = gemm_stages(BM, BN);
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int A_CH = BM / RPI, B_CH = BN / RPI;
+  constexpr int LPT = A_CH + B_CH;            // DMA instructions per thread per K tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -67,13 +73,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
   const bf16_t* __restrict__ B2p = (const bf16_t*)p.B2;
 
   const int c8 = tid & 7;       // 16-byte chunk inside the 64-wide K slice
-  const int row_base = tid >> 3;  // 0..31, +32 per chunk index
+  const int row_base = tid >> 3;  // 0..RPI-1, +RPI per chunk index
 
   ConvRow crow[A_CH];
   if (AMODE != MVIT_A_DENSE) {
 #pragma unroll
     for (int j = 0; j < A_CH; ++j) {
-      const int gm = m0 + row_base + 32 * j;
+      const int gm = m0 + row_base + RPI * j;
       crow[j].ok = gm < p.M;
       const int g = crow[j].ok ? gm : 0;
       crow[j].x = g % p.conv_OW;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
   // the K tail and the zero padding of the convolution window use an out-of-bounds offset (hardware returns 0).
   constexpr unsigned OOB = 0x80000000u;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int c8s = c8 ^ ((row_base >> 1) & 7);  // source chunk for this lane's LDS slot (same for every +32 row)
+  const int c8s = c8 ^ ((row_base >> 1) & 7);  // source chunk for this lane's LDS slot (same for every +RPI row)
   auto make_rsrc = [](const bf16_t* ptr) {
     // wave-uniform by construction (kernel arguments + blockIdx arithmetic); readfirstlane makes it provable so the
     // descriptor stays in SGPRs and hipcc does not wrap every buffer_load in a waterfall loop
@@ -114,13 +120,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
       const int ld = ext ? p.lda2 : p.lda;
 #pragma unroll
       for (int j = 0; j < A_CH; ++j) {
-        const int r = row_base + 32 * j;
+        const int r = row_base + RPI * j;
         const unsigned lin = ((unsigned)r * (unsigned)ld + (unsigned)k0) * 2u;
-        const unsigned off = (kok && m0 + r < p.M) ? lin : OOB;
+        unsigned off = (kok && m0 + r < p.M) ? lin : OOB;
+        asm volatile("" : "+v"(off));  // keep ONE unconditional DMA per chunk (the vmcnt accounting counts them)
         if constexpr (ext)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * RPI * 128), 16, off, 0, 0, 0);
         else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, 0, 0, 0);
       }
     } else {
       const int tap = k0 / p.conv_C, ch = k0 - tap * p.conv_C;
@@ -142,21 +149,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
         ok = ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W;
         const unsigned lin =
             (((unsigned)(crow[j].b * p.conv_H + iy) * (unsigned)p.conv_W + (unsigned)ix) * (unsigned)p.conv_ld + (unsigned)ch) * 2u;
-        const unsigned off = ok ? lin : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 32 * 128), 16, off, 0, 0, 0);
+        unsigned off = ok ? lin : OOB;
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, 0, 0, 0);
       }
     }
     {
       const int ld = ext ? p.ldb2 : p.ldb;
 #pragma unroll
       for (int j = 0; j < B_CH; ++j) {
-        const int r = row_base + 32 * j;
+        const int r = row_base + RPI * j;
         const unsigned lin = ((unsigned)r * (unsigned)ld + (unsigned)k0) * 2u;
-        const unsigned off = (kok && n0 + r < p.N) ? lin : OOB;
+        unsigned off = (kok && n0 + r < p.N) ? lin : OOB;
+        asm volatile("" : "+v"(off));
         if constexpr (ext)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * 32 * 128), 16, off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * RPI * 128), 16, off, 0, 0, 0);
         else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * 32 * 128), 16, off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * RPI * 128), 16, off, 0, 0, 0);
       }
     }
   };
@@ -178,11 +187,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
 
   const int frag_row = lane & 31, frag_half = lane >> 5;
 
-  issue_tile(t_begin, 0);
-  __syncthreads();
-  int cur = 0;
+  // ---- main loop: NSTAGE LDS buffers, NSTAGE-1 K tiles of DMA in flight.  Only counted vmcnt waits and a raw
+  // s_barrier (a __syncthreads() would drain the whole DMA queue): tile t is waited for by the waves that issued
+  // it, the barrier publishes it and also proves every wave is done reading the buffer refilled next.
+#pragma unroll
+  for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+    if (t_begin + s_ < t_end) issue_tile(t_begin + s_, s_);
+  int cur = 0, nxt = NSTAGE - 1;
   for (int t = t_begin; t < t_end; ++t) {
-    if (t + 1 < t_end) issue_tile(t + 1, cur ^ 1);  // lands while the MFMAs below run; drained before the barrier
+    if (NSTAGE == 3 && t + 1 < t_end)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NSTAGE - 1 < t_end) issue_tile(t + NSTAGE - 1, nxt);
     const char* a = smem + cur * BUF_BYTES;
     const char* b = a + A_BYTES;
 #pragma unroll
@@ -205,9 +223,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvit_gemm_args p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    cur ^= 1;
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
+  __syncthreads();  // LDS is reused by the statistics epilogue
 
   // ------------------------------------------------------------------ epilogue
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -339,8 +358,17 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 int launch_one(const mvit_gemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, 1, a.ksplit > 1 ? a.ksplit : 1);
-  const size_t lds = 2 * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>), grid, dim3(256), lds, s, a);
+  const size_t lds = (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
+  auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // per instantiation
+    if (!raised) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MVIT_EINVAL;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);
   return MVIT_LAUNCH_CHECK();
 }
 
