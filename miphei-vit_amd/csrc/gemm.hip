@@ -2,6 +2,8 @@
 #include <cstdlib>
 #include "gemm_kernel.hpp"
 
+static int dispatch(const mvit_gemm_args& a, hipStream_t s);
+
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   using namespace mvit_gemm;
@@ -17,6 +19,17 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   if ((a.epi == MVIT_EPI_DSWIGLU || a.epi == MVIT_EPI_DGELU) && !a.aux) return MVIT_EINVAL;
   if (a.epi == MVIT_EPI_PATCH && (!a.pos || a.patch_P <= 0)) return MVIT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  mvit_gemm_args al = a;  // vector (8/16-byte) epilogue I/O needs aligned pointers and leading dimensions
+  {
+    auto mis = [](const void* q, int ld) { return q && ((((uintptr_t)q) & 15) || (ld & 3)); };
+    if (mis(a.C, a.ldc) || mis(a.aux, a.ldaux) || mis(a.bias, 0) || mis(a.gamma, 0)) al.flags |= 0x400;
+    if (a.epi == MVIT_EPI_SWIGLU && (a.ldc & 3)) al.flags |= 0x400;
+  }
+  return dispatch(al, s);
+}
+
+static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
+  using namespace mvit_gemm;
   const bool dense = a.amode == MVIT_A_DENSE;
   static const int big_tile = [] { const char* e = getenv("MVIT_GEMM_BIG_TILE"); return e ? atoi(e) : 1; }();
   const bool big = big_tile && a.M >= 1024;  // 8-wave 256x128 tile, 3-stage DMA pipeline

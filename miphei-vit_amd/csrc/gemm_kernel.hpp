@@ -52,7 +52,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int tile_m = wg % tiles_m, tile_n = wg / tiles_m;
+  // grouped order: GROUP_M tile rows x all tile columns at a time, so the ~32 blocks resident on one XCD share few
+  // A / B panels per K step and its 4 MiB L2 serves most of the operand DMA
+  constexpr int GROUP_M = BM >= 256 ? 4 : 8;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int per_group = GROUP_M * tiles_n;
+  const int first_m = (wg / per_group) * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tile_m = first_m + (wg % per_group) % gsz, tile_n = (wg % per_group) / gsz;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- K range (split-K over blockIdx.z)
@@ -200,7 +207,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + NSTAGE - 1 < t_end) issue_tile(t + NSTAGE - 1, nxt);
+    if (t + NSTAGE - 1 < t_end && !(p.flags & 0x100)) issue_tile(t + NSTAGE - 1, nxt);
+    if (p.flags & 0x200) { cur = cur + 1 == NSTAGE ? 0 : cur + 1; nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1; continue; }
     const char* a = smem + cur * BUF_BYTES;
     const char* b = a + A_BYTES;
 #pragma unroll
@@ -229,136 +237,212 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   __syncthreads();  // LDS is reused by the statistics epilogue
 
   // ------------------------------------------------------------------ epilogue
-  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane owns single columns,
+  // so direct stores would be 2-byte scatters.  Instead every wave parks its accumulators in a private f32 LDS
+  // panel, re-reads them row-wise (4 consecutive columns per lane), applies the epilogue on float4s and stores
+  // 8-byte (bf16) / 16-byte (f32) pieces: 16 (or 8) lanes cover one contiguous row segment of the output.
+  constexpr int SLD = WTN + 4;                                   // panel row stride in floats (16-byte aligned)
+  constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 8 : WTN / 4;    // lanes per output row
+  constexpr int RPP = 64 / CPR;                                  // rows per pass
+  constexpr int PANEL = WTM * SLD;
+  float* stg = (float*)smem + (size_t)wave * PANEL;
   const int col_l = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_half) * SLD + j * 32 + col_l] = acc[i][j][r];
+
   const bool out_f32 = p.flags & MVIT_OUT_F32;
   const bool atomic = p.flags & MVIT_ATOMIC;
+  const bool scalar_io = p.flags & 0x400;  // set by the dispatcher when a pointer / leading dimension is not vector-aligned
   float* Cf = (float*)p.C;
   bf16_t* Cb = (bf16_t*)p.C;
+  const int lr = lane / CPR, lc = (lane % CPR) * 4;
+  const int colw = n0 + wave_n * WTN;  // first column of this wave's panel
 
-  if (EPI == MVIT_EPI_SWIGLU) {
-    if constexpr (TN == 2) {
-      bf16_t* aux = (bf16_t*)p.aux;
-      const int ca = n0 + wave_n * WTN + col_l, cb = ca + 32;
-      const int cg = ((n0 + wave_n * WTN) >> 1) + col_l;
-      const float bia = p.bias ? p.bias[ca] : 0.f, bib = p.bias ? p.bias[cb] : 0.f;
+  auto ld4bf = [&](const bf16_t* q, float (&o)[4]) {
+    if (!scalar_io) {
+      const uint2 t = *(const uint2*)q;
+      o[0] = __uint_as_float(t.x << 16), o[1] = __uint_as_float(t.x & 0xffff0000u);
+      o[2] = __uint_as_float(t.y << 16), o[3] = __uint_as_float(t.y & 0xffff0000u);
+    } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wave_m * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_half;
-          if (row < p.M) {
-            const float a_ = acc[i][0][r] + bia, b_ = acc[i][1][r] + bib;
-            if (aux) {
-              aux[(size_t)row * p.ldaux + ca] = f2bf(a_);
-              aux[(size_t)row * p.ldaux + cb] = f2bf(b_);
-            }
-            Cb[(size_t)row * p.ldc + cg] = f2bf(a_ * sigmoidf_(a_) * b_);
-          }
-        }
+      for (int e = 0; e < 4; ++e) o[e] = bf2f(q[e]);
     }
-    return;
-  }
+  };
+  auto st4bf = [&](bf16_t* q, const float (&o)[4], int nv) {
+    if (nv == 4 && !scalar_io) {
+      uint2 t;
+      t.x = pack2bf(o[0], o[1]);
+      t.y = pack2bf(o[2], o[3]);
+      *(uint2*)q = t;
+    } else {
+      for (int e = 0; e < nv; ++e) q[e] = f2bf(o[e]);
+    }
+  };
 
-  float st_s[TN], st_q[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) st_s[j] = st_q[j] = 0.f;
+  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (EPI == MVIT_EPI_SWIGLU) {
+    bf16_t* aux = (bf16_t*)p.aux;
+    const int ca = colw + lc, cb = ca + 32, cg = (colw >> 1) + lc;
+    float bia[4], bib[4];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wave_n * WTN + j * 32 + col_l;
-    const bool cok = col < p.N;
-    const float bias = (p.bias && cok) ? p.bias[col] : 0.f;
-    const float gam = (p.gamma && cok) ? p.gamma[col] : 1.f;
+    for (int e = 0; e < 4; ++e) bia[e] = p.bias ? p.bias[ca + e] : 0.f, bib[e] = p.bias ? p.bias[cb + e] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wave_m * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_half;
-        if (row >= p.M || !cok) continue;
-        float v = acc[i][j][r] + bias;
-        switch (EPI) {
-          case MVIT_EPI_STORE: {
-            const size_t o = (size_t)row * p.ldc + col;
-            if (atomic)
-              atomicAdd(Cf + o, v);
-            else if (out_f32)
-              Cf[o] = v;
-            else if (p.flags & MVIT_ACCUM_BF16)
-              Cb[o] = f2bf(bf2f(Cb[o]) + v);
-            else
-              Cb[o] = f2bf(v);
-          } break;
-          case MVIT_EPI_GELU: {
-            if (p.aux) ((bf16_t*)p.aux)[(size_t)row * p.ldaux + col] = f2bf(v);
-            Cb[(size_t)row * p.ldc + col] = f2bf(gelu_erf(v));
-          } break;
-          case MVIT_EPI_RESID: {
-            const size_t o = (size_t)row * p.ldc + col;
-            const float res = p.aux ? ((const float*)p.aux)[(size_t)row * p.ldaux + col] : Cf[o];
-            Cf[o] = res + gam * v;
-          } break;
-          case MVIT_EPI_PATCH: {
-            const int img = row / p.patch_P, pp = row - img * p.patch_P;
-            const size_t o = (size_t)(img * p.patch_ntok + p.patch_prefix + pp) * p.ldc + col;
-            Cf[o] = v + p.pos[(size_t)pp * p.N + col];
-          } break;
-          case MVIT_EPI_STATS: {
-            Cb[(size_t)row * p.ldc + col] = f2bf(v);
-            st_s[j] += v;
-            st_q[j] += v * v;
-          } break;
-          case MVIT_EPI_DSWIGLU: {
-            const bf16_t* u = (const bf16_t*)p.aux;
-            const int ca = ((col >> 5) << 6) + (col & 31);
-            const float a_ = bf2f(u[(size_t)row * p.ldaux + ca]), b_ = bf2f(u[(size_t)row * p.ldaux + ca + 32]);
-            const float sg = sigmoidf_(a_);
-            Cb[(size_t)row * p.ldc + ca] = f2bf(v * b_ * sg * (1.f + a_ * (1.f - sg)));
-            Cb[(size_t)row * p.ldc + ca + 32] = f2bf(v * a_ * sg);
-          } break;
-          case MVIT_EPI_DGELU: {
-            const float u = bf2f(((const bf16_t*)p.aux)[(size_t)row * p.ldaux + col]);
-            Cb[(size_t)row * p.ldc + col] = f2bf(v * gelu_erf_grad(u));
-          } break;
-          default: break;
-        }
+    for (int it = 0; it < WTM / RPP; ++it) {
+      const int rl = it * RPP + lr, row = m0 + wave_m * WTM + rl;
+      const float4 va = *(const float4*)(stg + rl * SLD + lc), vb = *(const float4*)(stg + rl * SLD + lc + 32);
+      if (row >= p.M) continue;
+      float a_[4] = {va.x + bia[0], va.y + bia[1], va.z + bia[2], va.w + bia[3]};
+      float b_[4] = {vb.x + bib[0], vb.y + bib[1], vb.z + bib[2], vb.w + bib[3]};
+      if (aux) {
+        st4bf(aux + (size_t)row * p.ldaux + ca, a_, 4);
+        st4bf(aux + (size_t)row * p.ldaux + cb, b_, 4);
       }
+      float g_[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g_[e] = a_[e] * sigmoidf_(a_[e]) * b_[e];
+      st4bf(Cb + (size_t)row * p.ldc + cg, g_, 4);
+    }
+  } else {
+    const int col = colw + lc;
+    const int nv = min(4, p.N - col);  // valid columns of this lane's quad (<= 0: none)
+    float bias[4], gam[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bias[e] = (p.bias && e < nv) ? p.bias[col + e] : 0.f;
+      gam[e] = (p.gamma && e < nv) ? p.gamma[col + e] : 1.f;
+    }
+#pragma unroll
+    for (int it = 0; it < WTM / RPP; ++it) {
+      const int rl = it * RPP + lr, row = m0 + wave_m * WTM + rl;
+      const float4 vv = *(const float4*)(stg + rl * SLD + lc);
+      if (row >= p.M || nv <= 0) continue;
+      float v[4] = {vv.x + bias[0], vv.y + bias[1], vv.z + bias[2], vv.w + bias[3]};
+      if constexpr (EPI == MVIT_EPI_STORE) {
+        const size_t o = (size_t)row * p.ldc + col;
+        if (atomic) {
+          for (int e = 0; e < nv; ++e) atomicAdd(Cf + o + e, v[e]);
+        } else if (out_f32) {
+          if (nv == 4 && !scalar_io)
+            *(float4*)(Cf + o) = make_float4(v[0], v[1], v[2], v[3]);
+          else
+            for (int e = 0; e < nv; ++e) Cf[o + e] = v[e];
+        } else {
+          if (p.flags & MVIT_ACCUM_BF16) {
+            if (nv == 4) {
+              float old[4];
+              ld4bf(Cb + o, old);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += old[e];
+            } else {
+              for (int e = 0; e < nv; ++e) v[e] += bf2f(Cb[o + e]);
+            }
+          }
+          st4bf(Cb + o, v, nv);
+        }
+      } else if constexpr (EPI == MVIT_EPI_GELU) {
+        if (p.aux) st4bf((bf16_t*)p.aux + (size_t)row * p.ldaux + col, v, nv);
+        float g_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g_[e] = gelu_erf(v[e]);
+        st4bf(Cb + (size_t)row * p.ldc + col, g_, nv);
+      } else if constexpr (EPI == MVIT_EPI_RESID) {
+        const size_t o = (size_t)row * p.ldc + col;
+        const float* rp = p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o;
+        if (nv == 4 && !scalar_io) {
+          const float4 r4 = *(const float4*)rp;
+          *(float4*)(Cf + o) = make_float4(r4.x + gam[0] * v[0], r4.y + gam[1] * v[1], r4.z + gam[2] * v[2], r4.w + gam[3] * v[3]);
+        } else {
+          for (int e = 0; e < nv; ++e) Cf[o + e] = rp[e] + gam[e] * v[e];
+        }
+      } else if constexpr (EPI == MVIT_EPI_PATCH) {
+        const int img = row / p.patch_P, pp = row - img * p.patch_P;
+        const size_t o = (size_t)(img * p.patch_ntok + p.patch_prefix + pp) * p.ldc + col;
+        for (int e = 0; e < nv; ++e) Cf[o + e] = v[e] + p.pos[(size_t)pp * p.N + col + e];
+      } else if constexpr (EPI == MVIT_EPI_STATS) {
+        st4bf(Cb + (size_t)row * p.ldc + col, v, nv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nv) st_s[e] += v[e], st_q[e] += v[e] * v[e];
+      } else if constexpr (EPI == MVIT_EPI_DSWIGLU) {
+        // gate columns col..col+3 live at packed positions ca.. (a) and ca+32.. (b) of the saved pre-activation
+        const bf16_t* u = (const bf16_t*)p.aux;
+        const int ca = ((col >> 5) << 6) + (col & 31);
+        float a_[4], b_[4], da[4], db[4];
+        ld4bf(u + (size_t)row * p.ldaux + ca, a_);
+        ld4bf(u + (size_t)row * p.ldaux + ca + 32, b_);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sg = sigmoidf_(a_[e]);
+          da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
+          db[e] = v[e] * a_[e] * sg;
+        }
+        st4bf(Cb + (size_t)row * p.ldc + ca, da, nv);
+        st4bf(Cb + (size_t)row * p.ldc + ca + 32, db, nv);
+      } else if constexpr (EPI == MVIT_EPI_DGELU) {
+        float u_[4] = {0.f, 0.f, 0.f, 0.f}, o_[4];
+        if (nv == 4)
+          ld4bf((const bf16_t*)p.aux + (size_t)row * p.ldaux + col, u_);
+        else
+          for (int e = 0; e < nv; ++e) u_[e] = bf2f(((const bf16_t*)p.aux)[(size_t)row * p.ldaux + col + e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o_[e] = v[e] * gelu_erf_grad(u_[e]);
+        st4bf(Cb + (size_t)row * p.ldc + col, o_, nv);
+      }
+    }
   }
 
-  if (EPI == MVIT_EPI_STATS) {
-    // per-column partials: lanes l / l^32 hold the same column; then across the WAVES_M waves via LDS
-    float* red = (float*)smem;  // [WAVES_M][BN][2]; main loop ended with a barrier, LDS is free
+  if constexpr (EPI == MVIT_EPI_STATS) {
+    // lanes with equal lane % CPR own the same 4 columns; then across the WAVES_M waves through LDS
+    float* red = (float*)smem + (size_t)(WAVES_M * WAVES_N) * PANEL;  // [WAVES_M][BN][2], behind the staging panels
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float s = st_s[j] + __shfl_xor(st_s[j], 32, 64);
-      const float q = st_q[j] + __shfl_xor(st_q[j], 32, 64);
-      if (lane < 32) {
-        const int c = wave_n * WTN + j * 32 + lane;
-        red[(wave_m * BN + c) * 2 + 0] = s;
-        red[(wave_m * BN + c) * 2 + 1] = q;
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        st_s[e] += __shfl_xor(st_s[e], o, 64);
+        st_q[e] += __shfl_xor(st_q[e], o, 64);
+      }
+    }
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = wave_n * WTN + lc + e;
+        red[(wave_m * BN + c) * 2 + 0] = st_s[e];
+        red[(wave_m * BN + c) * 2 + 1] = st_q[e];
       }
     }
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) {
-      double s = 0., q = 0.;
+      double s_ = 0., q_ = 0.;
 #pragma unroll
       for (int w = 0; w < WAVES_M; ++w) {
-        s += red[(w * BN + tid) * 2 + 0];
-        q += red[(w * BN + tid) * 2 + 1];
+        s_ += red[(w * BN + tid) * 2 + 0];
+        q_ += red[(w * BN + tid) * 2 + 1];
       }
       double* st = p.stats + (size_t)(blockIdx.x % p.nslots) * 2 * p.N;
-      atomicAdd(st + n0 + tid, s);
-      atomicAdd(st + p.N + n0 + tid, q);
+      atomicAdd(st + n0 + tid, s_);
+      atomicAdd(st + p.N + n0 + tid, q_);
     }
   }
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+constexpr size_t gemm_lds_bytes() {
+  constexpr size_t stages = (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
+  constexpr size_t panels = (size_t)(WAVES_M * WAVES_N) * (BM / WAVES_M) * (BN / WAVES_N + 4) * 4 + (size_t)WAVES_M * BN * 2 * 4;
+  return stages > panels ? stages : panels;
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 int launch_one(const mvit_gemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, 1, a.ksplit > 1 ? a.ksplit : 1);
-  const size_t lds = (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
+  const size_t lds = gemm_lds_bytes<BM, BN, WAVES_M, WAVES_N>();
   auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
   if (lds > 64 * 1024) {
     static bool raised = false;  // per instantiation
