@@ -21,9 +21,9 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   hipStream_t s = (hipStream_t)stream;
   mvit_gemm_args al = a;  // vector (8/16-byte) epilogue I/O needs aligned pointers and leading dimensions
   {
-    auto mis = [](const void* q, int ld) { return q && ((((uintptr_t)q) & 15) || (ld & 3)); };
+    auto mis = [](const void* q, int ld) { return q && ((((uintptr_t)q) & 15) || (ld & 7)); };
     if (mis(a.C, a.ldc) || mis(a.aux, a.ldaux) || mis(a.bias, 0) || mis(a.gamma, 0)) al.flags |= 0x400;
-    if (a.epi == MVIT_EPI_SWIGLU && (a.ldc & 3)) al.flags |= 0x400;
+    if (a.epi == MVIT_EPI_SWIGLU && (a.ldc & 7)) al.flags |= 0x400;
   }
   return dispatch(al, s);
 }

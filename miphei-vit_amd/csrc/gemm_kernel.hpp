@@ -201,6 +201,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
     if (t_begin + s_ < t_end) issue_tile(t_begin + s_, s_);
   int cur = 0, nxt = NSTAGE - 1;
+  if (p.flags & 0x1000) t_end = t_begin;  // debug: no main loop
   for (int t = t_begin; t < t_end; ++t) {
     if (NSTAGE == 3 && t + 1 < t_end)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
@@ -241,10 +242,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // so direct stores would be 2-byte scatters.  Instead every wave parks its accumulators in a private f32 LDS
   // panel, re-reads them row-wise (4 consecutive columns per lane), applies the epilogue on float4s and stores
   // 8-byte (bf16) / 16-byte (f32) pieces: 16 (or 8) lanes cover one contiguous row segment of the output.
-  constexpr int SLD = WTN + 4;                                   // panel row stride in floats (16-byte aligned)
-  constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 8 : WTN / 4;    // lanes per output row
-  constexpr int RPP = 64 / CPR;                                  // rows per pass
+  constexpr int SLD = WTN + 4;                                    // panel row stride in floats (16-byte aligned)
+  constexpr int V = 8;                                            // columns per lane: 16-byte bf16 stores
+  constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 32 / V : WTN / V;  // lanes per output row
+  constexpr int RPP = 64 / CPR;                                   // rows per pass
   constexpr int PANEL = WTM * SLD;
+  if (p.flags & 0x800) return;  // debug: no epilogue
   float* stg = (float*)smem + (size_t)wave * PANEL;
   const int col_l = lane & 31;
 #pragma unroll
@@ -260,148 +263,162 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   const bool scalar_io = p.flags & 0x400;  // set by the dispatcher when a pointer / leading dimension is not vector-aligned
   float* Cf = (float*)p.C;
   bf16_t* Cb = (bf16_t*)p.C;
-  const int lr = lane / CPR, lc = (lane % CPR) * 4;
+  const int lr = lane / CPR, lc = (lane % CPR) * V;
   const int colw = n0 + wave_n * WTN;  // first column of this wave's panel
 
-  auto ld4bf = [&](const bf16_t* q, float (&o)[4]) {
-    if (!scalar_io) {
-      const uint2 t = *(const uint2*)q;
-      o[0] = __uint_as_float(t.x << 16), o[1] = __uint_as_float(t.x & 0xffff0000u);
-      o[2] = __uint_as_float(t.y << 16), o[3] = __uint_as_float(t.y & 0xffff0000u);
+  auto ld8bf = [&](const bf16_t* q, float (&o)[V], int nv) {
+    if (nv == V && !scalar_io) {
+      const uint4 t = *(const uint4*)q;
+      const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = bf2f(q[e]);
+      for (int e = 0; e < V; ++e) o[e] = e < nv ? bf2f(q[e]) : 0.f;
     }
   };
-  auto st4bf = [&](bf16_t* q, const float (&o)[4], int nv) {
-    if (nv == 4 && !scalar_io) {
-      uint2 t;
-      t.x = pack2bf(o[0], o[1]);
-      t.y = pack2bf(o[2], o[3]);
-      *(uint2*)q = t;
+  auto st8bf = [&](bf16_t* q, const float (&o)[V], int nv) {
+    if (nv == V && !scalar_io) {
+      uint4 t;
+      t.x = pack2bf(o[0], o[1]), t.y = pack2bf(o[2], o[3]), t.z = pack2bf(o[4], o[5]), t.w = pack2bf(o[6], o[7]);
+      *(uint4*)q = t;
     } else {
       for (int e = 0; e < nv; ++e) q[e] = f2bf(o[e]);
     }
   };
+  auto ld8f = [&](const float* q, float (&o)[V], int nv) {
+    if (nv == V && !scalar_io) {
+      const float4 t0 = ((const float4*)q)[0], t1 = ((const float4*)q)[1];
+      o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = e < nv ? q[e] : 0.f;
+    }
+  };
+  auto st8f = [&](float* q, const float (&o)[V], int nv) {
+    if (nv == V && !scalar_io) {
+      ((float4*)q)[0] = make_float4(o[0], o[1], o[2], o[3]);
+      ((float4*)q)[1] = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+      for (int e = 0; e < nv; ++e) q[e] = o[e];
+    }
+  };
+  auto panel8 = [&](int rl, int c0, float (&o)[V]) {
+    const float4 t0 = *(const float4*)(stg + rl * SLD + c0), t1 = *(const float4*)(stg + rl * SLD + c0 + 4);
+    o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
+  };
 
-  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+  float st_s[V], st_q[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) st_s[e] = st_q[e] = 0.f;
 
   if constexpr (EPI == MVIT_EPI_SWIGLU) {
     bf16_t* aux = (bf16_t*)p.aux;
     const int ca = colw + lc, cb = ca + 32, cg = (colw >> 1) + lc;
-    float bia[4], bib[4];
+    float bia[V], bib[V];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bia[e] = p.bias ? p.bias[ca + e] : 0.f, bib[e] = p.bias ? p.bias[cb + e] : 0.f;
+    for (int e = 0; e < V; ++e) bia[e] = p.bias ? p.bias[ca + e] : 0.f, bib[e] = p.bias ? p.bias[cb + e] : 0.f;
 #pragma unroll
     for (int it = 0; it < WTM / RPP; ++it) {
       const int rl = it * RPP + lr, row = m0 + wave_m * WTM + rl;
-      const float4 va = *(const float4*)(stg + rl * SLD + lc), vb = *(const float4*)(stg + rl * SLD + lc + 32);
+      float a_[V], b_[V], g_[V];
+      panel8(rl, lc, a_);
+      panel8(rl, lc + 32, b_);
       if (row >= p.M) continue;
-      float a_[4] = {va.x + bia[0], va.y + bia[1], va.z + bia[2], va.w + bia[3]};
-      float b_[4] = {vb.x + bib[0], vb.y + bib[1], vb.z + bib[2], vb.w + bib[3]};
-      if (aux) {
-        st4bf(aux + (size_t)row * p.ldaux + ca, a_, 4);
-        st4bf(aux + (size_t)row * p.ldaux + cb, b_, 4);
-      }
-      float g_[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g_[e] = a_[e] * sigmoidf_(a_[e]) * b_[e];
-      st4bf(Cb + (size_t)row * p.ldc + cg, g_, 4);
+      for (int e = 0; e < V; ++e) a_[e] += bia[e], b_[e] += bib[e];
+      if (aux) {
+        st8bf(aux + (size_t)row * p.ldaux + ca, a_, V);
+        st8bf(aux + (size_t)row * p.ldaux + cb, b_, V);
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) g_[e] = a_[e] * sigmoidf_(a_[e]) * b_[e];
+      st8bf(Cb + (size_t)row * p.ldc + cg, g_, V);
     }
   } else {
     const int col = colw + lc;
-    const int nv = min(4, p.N - col);  // valid columns of this lane's quad (<= 0: none)
-    float bias[4], gam[4];
+    const int nv = min(V, p.N - col);  // valid columns of this lane's group (<= 0: none)
+    float bias[V], gam[V];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < V; ++e) {
       bias[e] = (p.bias && e < nv) ? p.bias[col + e] : 0.f;
       gam[e] = (p.gamma && e < nv) ? p.gamma[col + e] : 1.f;
     }
 #pragma unroll
     for (int it = 0; it < WTM / RPP; ++it) {
       const int rl = it * RPP + lr, row = m0 + wave_m * WTM + rl;
-      const float4 vv = *(const float4*)(stg + rl * SLD + lc);
+      float v[V];
+      panel8(rl, lc, v);
       if (row >= p.M || nv <= 0) continue;
-      float v[4] = {vv.x + bias[0], vv.y + bias[1], vv.z + bias[2], vv.w + bias[3]};
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += bias[e];
       if constexpr (EPI == MVIT_EPI_STORE) {
         const size_t o = (size_t)row * p.ldc + col;
         if (atomic) {
           for (int e = 0; e < nv; ++e) atomicAdd(Cf + o + e, v[e]);
         } else if (out_f32) {
-          if (nv == 4 && !scalar_io)
-            *(float4*)(Cf + o) = make_float4(v[0], v[1], v[2], v[3]);
-          else
-            for (int e = 0; e < nv; ++e) Cf[o + e] = v[e];
+          st8f(Cf + o, v, nv);
         } else {
           if (p.flags & MVIT_ACCUM_BF16) {
-            if (nv == 4) {
-              float old[4];
-              ld4bf(Cb + o, old);
+            float old[V];
+            ld8bf(Cb + o, old, nv);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += old[e];
-            } else {
-              for (int e = 0; e < nv; ++e) v[e] += bf2f(Cb[o + e]);
-            }
+            for (int e = 0; e < V; ++e) v[e] += old[e];
           }
-          st4bf(Cb + o, v, nv);
+          st8bf(Cb + o, v, nv);
         }
       } else if constexpr (EPI == MVIT_EPI_GELU) {
-        if (p.aux) st4bf((bf16_t*)p.aux + (size_t)row * p.ldaux + col, v, nv);
-        float g_[4];
+        if (p.aux) st8bf((bf16_t*)p.aux + (size_t)row * p.ldaux + col, v, nv);
+        float g_[V];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g_[e] = gelu_erf(v[e]);
-        st4bf(Cb + (size_t)row * p.ldc + col, g_, nv);
+        for (int e = 0; e < V; ++e) g_[e] = gelu_erf(v[e]);
+        st8bf(Cb + (size_t)row * p.ldc + col, g_, nv);
       } else if constexpr (EPI == MVIT_EPI_RESID) {
         const size_t o = (size_t)row * p.ldc + col;
-        const float* rp = p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o;
-        if (nv == 4 && !scalar_io) {
-          const float4 r4 = *(const float4*)rp;
-          *(float4*)(Cf + o) = make_float4(r4.x + gam[0] * v[0], r4.y + gam[1] * v[1], r4.z + gam[2] * v[2], r4.w + gam[3] * v[3]);
-        } else {
-          for (int e = 0; e < nv; ++e) Cf[o + e] = rp[e] + gam[e] * v[e];
-        }
+        float r_[V];
+        ld8f(p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o, r_, nv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) r_[e] += gam[e] * v[e];
+        st8f(Cf + o, r_, nv);
       } else if constexpr (EPI == MVIT_EPI_PATCH) {
         const int img = row / p.patch_P, pp = row - img * p.patch_P;
         const size_t o = (size_t)(img * p.patch_ntok + p.patch_prefix + pp) * p.ldc + col;
         for (int e = 0; e < nv; ++e) Cf[o + e] = v[e] + p.pos[(size_t)pp * p.N + col + e];
       } else if constexpr (EPI == MVIT_EPI_STATS) {
-        st4bf(Cb + (size_t)row * p.ldc + col, v, nv);
+        st8bf(Cb + (size_t)row * p.ldc + col, v, nv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < V; ++e)
           if (e < nv) st_s[e] += v[e], st_q[e] += v[e] * v[e];
       } else if constexpr (EPI == MVIT_EPI_DSWIGLU) {
-        // gate columns col..col+3 live at packed positions ca.. (a) and ca+32.. (b) of the saved pre-activation
+        // gate columns col..col+7 live at packed positions ca.. (a) and ca+32.. (b) of the saved pre-activation
         const bf16_t* u = (const bf16_t*)p.aux;
         const int ca = ((col >> 5) << 6) + (col & 31);
-        float a_[4], b_[4], da[4], db[4];
-        ld4bf(u + (size_t)row * p.ldaux + ca, a_);
-        ld4bf(u + (size_t)row * p.ldaux + ca + 32, b_);
+        float a_[V], b_[V], da[V], db[V];
+        ld8bf(u + (size_t)row * p.ldaux + ca, a_, nv);
+        ld8bf(u + (size_t)row * p.ldaux + ca + 32, b_, nv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
           const float sg = sigmoidf_(a_[e]);
           da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
           db[e] = v[e] * a_[e] * sg;
         }
-        st4bf(Cb + (size_t)row * p.ldc + ca, da, nv);
-        st4bf(Cb + (size_t)row * p.ldc + ca + 32, db, nv);
+        st8bf(Cb + (size_t)row * p.ldc + ca, da, nv);
+        st8bf(Cb + (size_t)row * p.ldc + ca + 32, db, nv);
       } else if constexpr (EPI == MVIT_EPI_DGELU) {
-        float u_[4] = {0.f, 0.f, 0.f, 0.f}, o_[4];
-        if (nv == 4)
-          ld4bf((const bf16_t*)p.aux + (size_t)row * p.ldaux + col, u_);
-        else
-          for (int e = 0; e < nv; ++e) u_[e] = bf2f(((const bf16_t*)p.aux)[(size_t)row * p.ldaux + col + e]);
+        float u_[V], o_[V];
+        ld8bf((const bf16_t*)p.aux + (size_t)row * p.ldaux + col, u_, nv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o_[e] = v[e] * gelu_erf_grad(u_[e]);
-        st4bf(Cb + (size_t)row * p.ldc + col, o_, nv);
+        for (int e = 0; e < V; ++e) o_[e] = v[e] * gelu_erf_grad(u_[e]);
+        st8bf(Cb + (size_t)row * p.ldc + col, o_, nv);
       }
     }
   }
 
   if constexpr (EPI == MVIT_EPI_STATS) {
-    // lanes with equal lane % CPR own the same 4 columns; then across the WAVES_M waves through LDS
+    // lanes with equal lane % CPR own the same V columns; then across the WAVES_M waves through LDS
     float* red = (float*)smem + (size_t)(WAVES_M * WAVES_N) * PANEL;  // [WAVES_M][BN][2], behind the staging panels
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < V; ++e) {
 #pragma unroll
       for (int o = CPR; o < 64; o <<= 1) {
         st_s[e] += __shfl_xor(st_s[e], o, 64);
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     }
     if (lane < CPR) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < V; ++e) {
         const int c = wave_n * WTN + lc + e;
         red[(wave_m * BN + c) * 2 + 0] = st_s[e];
         red[(wave_m * BN + c) * 2 + 1] = st_q[e];
