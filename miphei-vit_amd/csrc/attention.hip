@@ -135,26 +135,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
       }
     }
-    // online softmax (log2 domain)
-    float mloc = -1e30f;
+    // online softmax (log2 domain): p = 2^(s*sc - m); the key mask is only needed in the ragged last tile
+    if (kv0 + KVB > N) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= N) st[kt][r] = -1e30f;
+        }
+    }
+    float mloc = st[0][0];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float v = key < N ? st[kt][r] * sc : -1e30f;
-        st[kt][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
+    mloc = fmaxf(mloc * sc, -1e30f);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(st[kt][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -m_new));
         st[kt][r] = p;
         lsum += p;
       }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float p = key < N ? exp2f(st[kt][r] * sc - Lq) : 0.f;
+        const float p = key < N ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -Lq)) : 0.f;
         st[kt][r] = p * (dp[kt][r] - Dq) * dm.scale;  // dS^T
       }
     }
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float p = (qt0 + ql < N) ? exp2f(st[qt][r] * sc - Ls[ql]) : 0.f;
+        const float p = (qt0 + ql < N) ? __builtin_amdgcn_exp2f(fmaf(st[qt][r], sc, -Ls[ql])) : 0.f;
         st[qt][r] = p;                                          // P
         dp[qt][r] = p * (dp[qt][r] - Ls[64 + ql]) * dm.scale;  // dS
       }

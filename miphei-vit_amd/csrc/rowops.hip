@@ -195,28 +195,34 @@ __global__ __launch_bounds__(256) void skinny_xty_kernel(const bf16_t* __restric
     for (int q = 0; q < 4; ++q) acc[r][q] = 0.f;
   const bool full = n0 + 3 < N;
   if (n0 < N) {
-#pragma unroll 4
-    for (int i = wave; i < XTY_ROWS; i += 4) {
-      const int m = mbeg + i;
-      if (m >= M) break;
-      float y[4];
-      if (full) {
-        const uint2 t = *(const uint2*)(Y + (size_t)m * ldy + n0);
-        y[0] = __uint_as_float(t.x << 16), y[1] = __uint_as_float(t.x & 0xffff0000u);
-        y[2] = __uint_as_float(t.y << 16), y[3] = __uint_as_float(t.y & 0xffff0000u);
-      } else {
+    // rows wave, wave+4, ...: 8 row loads in flight per lane (rows past M are clamped; their X rows are zero in LDS)
+    constexpr int UN = 8;
+    for (int i0 = wave; i0 < XTY_ROWS; i0 += 4 * UN) {
+      float y[UN][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = n0 + q < N ? bf2f(Y[(size_t)m * ldy + n0 + q]) : 0.f;
+      for (int u = 0; u < UN; ++u) {
+        const int m = min(mbeg + i0 + 4 * u, M - 1);
+        if (full) {
+          const uint2 t = *(const uint2*)(Y + (size_t)m * ldy + n0);
+          y[u][0] = __uint_as_float(t.x << 16), y[u][1] = __uint_as_float(t.x & 0xffff0000u);
+          y[u][2] = __uint_as_float(t.y << 16), y[u][3] = __uint_as_float(t.y & 0xffff0000u);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[u][q] = n0 + q < N ? bf2f(Y[(size_t)m * ldy + n0 + q]) : 0.f;
+        }
       }
-      const float4* xr = (const float4*)xs[i];
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 xv = xr[r4];
-        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+      for (int u = 0; u < UN; ++u) {
+        const float4* xr = (const float4*)xs[i0 + 4 * u];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float4 xv = xr[r4];
+          const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[r4 * 4 + k][q] += xx[k] * y[q];
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r4 * 4 + k][q] += xx[k] * y[u][q];
+        }
       }
     }
   }
