@@ -11,7 +11,7 @@ from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, ACCUM_BF16, ATOMIC, EPI_DGELU, E
 
 
 class _Probe:
-    """Optional HIP-event timing of the dominant kernel (dense 128x128 MFMA GEMM, plain store epilogue) for bench.py."""
+    """Optional HIP-event timing of the dominant kernel (dense MFMA GEMM, plain store epilogue) for bench.py."""
 
     def __init__(self):
         self.on = False

@@ -1,0 +1,23 @@
+"""Attention fwd/bwd at the H-Optimus-0 shape (B=16, N=329, H=24, Dh=64): timing + achieved TFLOP/s."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import miphei_vit_amd.ops as ops
+B, N, H, Dh = 16, int(sys.argv[1]) if len(sys.argv) > 1 else 329, 24, 64
+qkv = torch.randn(B, N, 3, H, Dh, device="cuda").bfloat16()
+out = torch.empty(B, N, H * Dh, device="cuda", dtype=torch.bfloat16)
+lse = torch.empty(B, H, N, device="cuda")
+dO = torch.randn_like(out); dqkv = torch.empty_like(qkv); dsum = torch.empty_like(lse)
+sc = Dh ** -0.5
+def t(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+f = t(lambda: ops.attention_fwd(qkv, out, lse, B, N, H, Dh, sc))
+b = t(lambda: ops.attention_bwd(qkv, out, dO, lse, dsum, dqkv, B, N, H, Dh, sc))
+fl = 4.0 * B * H * N * N * Dh
+print(f"N={N} fwd {f*1e3:.1f} us ({fl/f/1e9:.1f} TF/s)   bwd {b*1e3:.1f} us ({2.5*fl/b/1e9:.1f} TF/s useful)")
