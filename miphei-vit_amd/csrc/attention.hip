@@ -46,23 +46,26 @@ struct AttnDims {
   float scale;
 };
 
-// stage one 64-row tile (rows row0.. of matrix `which` of the packed qkv) into registers / LDS
-__device__ __forceinline__ void load_rows(const bf16_t* __restrict__ base, size_t row_stride, int row0, int nrows_valid,
-                                          int Dh, int tid, uint4 (&r)[2]) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int id = tid + 256 * j, row = id >> 3, c = id & 7;
-    if (row0 + row < nrows_valid && c * 8 < Dh)
-      r[j] = *(const uint4*)(base + (size_t)(row0 + row) * row_stride + c * 8);
-    else
-      r[j] = make_uint4(0, 0, 0, 0);
-  }
+// DMA one 64-row x 64-col bf16 tile (rows row0.. of a matrix with row stride `rs` elements) straight into LDS
+// (buffer_load ... lds, 16 B per lane): lane l of a wave fills row l>>3, 16-byte slot l&7 of 8 consecutive rows; the
+// XOR swizzle is applied to the SOURCE chunk (slot s of row r holds chunk s ^ ((r>>1)&7)); rows >= nvalid and
+// columns >= Dh come back as zeros through an out-of-range offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const bf16_t* ptr) {
+  const unsigned long long v = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ void store_rows(char* tile, int tid, const uint4 (&r)[2]) {
+__device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rsrc, char* tile, int row0, int nvalid, int Dh,
+                                         unsigned rs, int tid) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int id = tid + 256 * j, row = id >> 3, c = id & 7;
-    *(uint4*)(tile + swz(row, c)) = r[j];
+    const int row = 8 * wave_u + 32 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    unsigned off = (row0 + row < nvalid && c * 8 < Dh) ? ((unsigned)(row0 + row) * rs + (unsigned)c * 8u) * 2u : 0x80000000u;
+    asm volatile("" : "+v"(off));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(tile + (8 * wave_u + 32 * j) * 128), 16, off, 0, 0, 0);
   }
 }
 
@@ -106,19 +109,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   float m_run = -1e30f, l_run = 0.f;
   const float sc = dm.scale * LOG2E;
 
-  uint4 rk[2], rv[2];
   const int ntiles = (N + KVB - 1) / KVB;
-  load_rows(kb, rs, 0, N, Dh, tid, rk);
-  load_rows(vb, rs, 0, N, Dh, tid, rv);
-  store_rows(smem, tid, rk);
-  store_rows(smem + TILE_BYTES, tid, rv);
+  const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
+  dma_rows(rK, smem, 0, N, Dh, (unsigned)rs, tid);
+  dma_rows(rV, smem + TILE_BYTES, 0, N, Dh, (unsigned)rs, tid);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const bool more = t + 1 < ntiles;
     if (more) {
-      load_rows(kb, rs, (t + 1) * KVB, N, Dh, tid, rk);
-      load_rows(vb, rs, (t + 1) * KVB, N, Dh, tid, rv);
+      dma_rows(rK, smem + (cur ^ 1) * 2 * TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
+      dma_rows(rV, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
     }
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
@@ -184,10 +185,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         const bf16x8 a = join(tr_read4(Vs, kbase, cb, lane), tr_read4(Vs, kbase + 8, cb, lane));
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[dt], 0, 0, 0);
       }
-    }
-    if (more) {
-      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES, tid, rk);
-      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, tid, rv);
     }
     __syncthreads();
   }
@@ -275,19 +272,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
-  uint4 rk[2], rv[2];
   const int ntiles = (N + KVB - 1) / KVB;
-  load_rows(kb, rs, 0, N, Dh, tid, rk);
-  load_rows(vb, rs, 0, N, Dh, tid, rv);
-  store_rows(smem, tid, rk);
-  store_rows(smem + TILE_BYTES, tid, rv);
+  const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
+  dma_rows(rK, smem, 0, N, Dh, (unsigned)rs, tid);
+  dma_rows(rV, smem + TILE_BYTES, 0, N, Dh, (unsigned)rs, tid);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const bool more = t + 1 < ntiles;
     if (more) {
-      load_rows(kb, rs, (t + 1) * KVB, N, Dh, tid, rk);
-      load_rows(vb, rs, (t + 1) * KVB, N, Dh, tid, rv);
+      dma_rows(rK, smem + (cur ^ 1) * 2 * TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
+      dma_rows(rV, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
     }
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
@@ -325,10 +320,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         const bf16x8 a = join(tr_read4(Ks, kbase, cb, lane), tr_read4(Ks, kbase + 8, cb, lane));
         dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb, dqacc[dt], 0, 0, 0);
       }
-    }
-    if (more) {
-      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES, tid, rk);
-      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, tid, rv);
     }
     __syncthreads();
   }
@@ -386,8 +377,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) dkacc[i][r] = 0.f, dvacc[i][r] = 0.f;
 
-  uint4 rq[2], rd[2];
   float rl = 0.f;
+  const __amdgpu_buffer_rsrc_t rQ = make_rsrc(qb), rD = make_rsrc(dob);
   const int ntiles = (N + KVB - 1) / KVB;
   auto load_ld = [&](int row0) {
     // threads 0..63: L, 64..127: D
@@ -399,19 +390,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   auto store_ld = [&](int buf) {
     if (tid < 128) LD[buf * 128 + tid] = rl;
   };
-  load_rows(qb, rs, 0, N, Dh, tid, rq);
-  load_rows(dob, ors, 0, N, Dh, tid, rd);
+  dma_rows(rQ, smem, 0, N, Dh, (unsigned)rs, tid);
+  dma_rows(rD, smem + TILE_BYTES, 0, N, Dh, (unsigned)ors, tid);
   load_ld(0);
-  store_rows(smem, tid, rq);
-  store_rows(smem + TILE_BYTES, tid, rd);
   store_ld(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const bool more = t + 1 < ntiles;
     if (more) {
-      load_rows(qb, rs, (t + 1) * KVB, N, Dh, tid, rq);
-      load_rows(dob, ors, (t + 1) * KVB, N, Dh, tid, rd);
+      dma_rows(rQ, smem + (cur ^ 1) * 2 * TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
+      dma_rows(rD, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)ors, tid);
       load_ld((t + 1) * KVB);
     }
     const char* Qs = smem + cur * 2 * TILE_BYTES;
@@ -431,11 +420,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, vf[s], dp[qt], 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float p = (qt0 + ql < N) ? __builtin_amdgcn_exp2f(fmaf(st[qt][r], sc, -Ls[ql])) : 0.f;
-        st[qt][r] = p;                                          // P
-        dp[qt][r] = p * (dp[qt][r] - Ls[64 + ql]) * dm.scale;  // dS
+      for (int g = 0; g < 4; ++g) {
+        const int qb4 = 32 * qt + 8 * g + 4 * half;  // 4 consecutive query rows per register group
+        const float4 L4 = *(const float4*)(Ls + qb4), D4 = *(const float4*)(Ls + 64 + qb4);
+        const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv_[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float p = (qt0 + qb4 + e < N) ? __builtin_amdgcn_exp2f(fmaf(st[qt][r], sc, -Lv[e])) : 0.f;
+          st[qt][r] = p;                                      // P
+          dp[qt][r] = p * (dp[qt][r] - Dv_[e]) * dm.scale;   // dS
+        }
       }
     }
 #pragma unroll
@@ -455,11 +450,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb, dkacc[dt], 0, 0, 0);
       }
     }
-    if (more) {
-      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES, tid, rq);
-      store_rows(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, tid, rd);
-      store_ld(cur ^ 1);
-    }
+    if (more) store_ld(cur ^ 1);
     __syncthreads();
   }
   if (key < N) {
