@@ -66,6 +66,22 @@ typedef struct mvit_gemm_args {
 
 MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream);
 
+/*
+ * C(f32)[i*ldci + j*ldcj] += sum_m A[m,i] * B[m,j]: both operands m-major bf16 (the contraction runs over ROWS), MFMA
+ * fragments gathered with ds_read_b64_tr_b16.  amode DENSE: A = [M, I] (lda).  amode CONV3: A = virtual im2col of an
+ * NHWC activation [B, conv_H, conv_W, conv_ld] (3x3, pad 1, stride conv_stride), row m = output pixel (b,oy,ox),
+ * I = 9*conv_C.  msplit blocks share the M range (f32 atomics; C must be pre-zeroed or hold the running sum).
+ * Weight gradients of nn.Conv2d (src/generators/mipheivit.py:32,86), LoRA dA/dB (src/generators/lora.py:11-12) and the
+ * head convolutions (src/generators/unet.py:431), i.e. the parameter side of loss.backward() (src/models.py:135).
+ */
+typedef struct mvit_gemm_tn_args {
+  const void* A; const void* B; float* C;
+  long long ldci, ldcj;
+  int M, I, J, lda, ldb, amode, msplit;
+  int conv_H, conv_W, conv_C, conv_ld, conv_OH, conv_OW, conv_stride;
+} mvit_gemm_tn_args;
+MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_stream_t stream);
+
 /* ---------------------------------------------------------------- row-wise encoder kernels */
 /* out(bf16)[M,D] = LayerNorm(x f32 [M,D]) * w + b, biased variance, eps inside the sqrt.
  * Replaces timm Block.norm1/norm2 and VisionTransformer.norm (nn.LayerNorm eps 1e-6) reached through

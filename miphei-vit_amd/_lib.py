@@ -32,9 +32,17 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmTnArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("ldci", ll), ("ldcj", ll),
+                ("M", ci), ("I", ci), ("J", ci), ("lda", ci), ("ldb", ci), ("amode", ci), ("msplit", ci),
+                ("conv_H", ci), ("conv_W", ci), ("conv_C", ci), ("conv_ld", ci), ("conv_OH", ci), ("conv_OW", ci),
+                ("conv_stride", ci)]
+
+
 # name -> argtypes (restype is always int); mirrors include/miphei_hip.h
 SIGNATURES = {
     "mvit_gemm_bf16": [C.POINTER(GemmArgs), vp],
+    "mvit_gemm_tn_bf16": [C.POINTER(GemmTnArgs), vp],
     "mvit_layernorm_fwd": [vp, vp, vp, vp, ci, ci, cf, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
     "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],

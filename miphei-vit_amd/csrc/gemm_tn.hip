@@ -1,0 +1,189 @@
+// "TN" MFMA GEMM for weight gradients:  C[i,j] += sum_m A[m,i] * B[m,j]   (f32 atomic accumulate)
+//
+// Both operands are stored m-major (activations / gradients as produced by the forward and backward passes), so the
+// contraction index is the ROW index of both.  Tiles [64 m][64 cols] are DMA'd into LDS as they lie in memory and the
+// MFMA fragments (8 consecutive m per lane for a fixed column) are gathered with the gfx950 transpose read
+// ds_read_b64_tr_b16 -- no transposed copies of the operands, no im2col buffer:
+//   * decoder conv weight gradients: A = virtual im2col of the NHWC input (3x3 window gather, as the forward loader),
+//     B = dY [pixels, Cout]   ->  dW^T [(ky,kx,c), Cout]
+//   * LoRA dA = dt^T h, dB = t^T dq and the head conv dW3 = E^T x (A dense).
+// 4 waves, tile 64(i) x 128(j) or 128(i) x 32(j), 64 rows of m per step, 2 LDS stages, split over m (blockIdx.z).
+#include "common.hpp"
+#include "../../include/miphei_hip.h"
+
+namespace {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+constexpr int BLK_BYTES = 64 * 128;  // one [64 m][64 col] bf16 block
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ v4s tr_read4(const char* tile, int row_base, int col_base16, int lane) {
+  const int i = lane & 15;
+  const int row = row_base + (i >> 2);
+  const int col = col_base16 + 4 * (i & 3);
+  const char* p = tile + swz(row, col >> 3) + ((col & 7) << 1);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
+}
+__device__ __forceinline__ bf16x8 join(v4s a, v4s b) {
+  union { struct { v4s lo, hi; } s; bf16x8 v; } u;
+  u.s.lo = a;
+  u.s.hi = b;
+  return u.v;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr) {
+  const unsigned long long v = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int IT, int JT, int AMODE>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p) {
+  constexpr int WI = IT / 32 >= 4 ? 4 : IT / 32;  // waves along i
+  constexpr int WJ = 4 / WI;
+  constexpr int WJT = JT / WJ;                     // columns per wave
+  constexpr int TN = WJT / 32;
+  constexpr int ABLK = IT / 64, BBLK = (JT + 63) / 64;
+  constexpr int STAGE = (ABLK + BBLK) * BLK_BYTES;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wave_i = wave / WJ, wave_j = wave % WJ;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int i0 = blockIdx.x * IT, j0 = blockIdx.y * JT;
+  const long long nsteps = ((long long)p.M + 63) / 64;
+  const long long per = (nsteps + gridDim.z - 1) / gridDim.z;
+  const long long s_begin = blockIdx.z * per, s_end = min(nsteps, s_begin + per);
+  if (s_begin >= s_end) return;
+  const bf16_t* Ap = (const bf16_t*)p.A;
+  const bf16_t* Bp = (const bf16_t*)p.B;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(AMODE == MVIT_A_DENSE ? (const void*)(Ap + (size_t)s_begin * 64 * p.lda) : (const void*)Ap);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(Bp + (size_t)s_begin * 64 * p.ldb);
+
+  auto issue = [&](long long st, int buf) {
+    char* a = smem + buf * STAGE;
+    char* b = a + ABLK * BLK_BYTES;
+    const int mrel0 = (int)((st - s_begin) * 64);  // row offset relative to the descriptor base
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 8 * wave_u + 32 * j + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      const long long m = st * 64 + row;
+      const bool mok = m < p.M;
+      // ---- A blocks
+      int pb = 0, py = 0, px = 0;
+      if (AMODE != MVIT_A_DENSE) {
+        const long long mm = mok ? m : 0;
+        px = (int)(mm % p.conv_OW);
+        const long long t = mm / p.conv_OW;
+        py = (int)(t % p.conv_OH);
+        pb = (int)(t / p.conv_OH);
+      }
+#pragma unroll
+      for (int ab = 0; ab < ABLK; ++ab) {
+        const int icol = i0 + ab * 64 + c * 8;
+        unsigned off = 0x80000000u;
+        if (mok && icol < p.I) {
+          if (AMODE == MVIT_A_DENSE) {
+            off = ((unsigned)(mrel0 + row) * (unsigned)p.lda + (unsigned)icol) * 2u;
+          } else {
+            const int tap = icol / p.conv_C, ch = icol - tap * p.conv_C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int iy = py * p.conv_stride + ky - 1, ix = px * p.conv_stride + kx - 1;
+            if (iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W)
+              off = (((unsigned)(pb * p.conv_H + iy) * (unsigned)p.conv_W + (unsigned)ix) * (unsigned)p.conv_ld + (unsigned)ch) * 2u;
+          }
+        }
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + ab * BLK_BYTES + (8 * wave_u + 32 * j) * 128), 16, off, 0, 0, 0);
+      }
+#pragma unroll
+      for (int bb = 0; bb < BBLK; ++bb) {
+        const int jcol = j0 + bb * 64 + c * 8;
+        unsigned off = (mok && jcol < p.J) ? ((unsigned)(mrel0 + row) * (unsigned)p.ldb + (unsigned)jcol) * 2u : 0x80000000u;
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + bb * BLK_BYTES + (8 * wave_u + 32 * j) * 128), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // fragment addressing: this lane's column inside its 64-column block
+  const int il = wave_i * 32;                       // first i of the wave inside the tile
+  const char* const a_off = (const char*)0 + (il / 64) * BLK_BYTES;
+  const int a_cb = (il % 64) + 16 * ((lane >> 4) & 1);
+
+  issue(s_begin, 0);
+  __syncthreads();
+  int cur = 0;
+  for (long long st = s_begin; st < s_end; ++st) {
+    if (st + 1 < s_end) issue(st + 1, cur ^ 1);
+    const char* a = smem + cur * STAGE + (size_t)a_off;
+    const char* b = smem + cur * STAGE + ABLK * BLK_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int mb = 16 * s + 4 * half;
+      const bf16x8 fa = join(tr_read4(a, mb, a_cb, lane), tr_read4(a, mb + 8, a_cb, lane));
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int jl = wave_j * WJT + t * 32;
+        const char* bt = b + (jl / 64) * BLK_BYTES;
+        const int b_cb = (jl % 64) + 16 * ((lane >> 4) & 1);
+        const bf16x8 fb = join(tr_read4(bt, mb, b_cb, lane), tr_read4(bt, mb + 8, b_cb, lane));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*half
+  float* C = (float*)p.C;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int j = j0 + wave_j * WJT + t * 32 + l31;
+    if (j >= p.J) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + il + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (i < p.I) atomicAdd(C + (size_t)i * p.ldci + (size_t)j * p.ldcj, acc[t][r]);
+    }
+  }
+}
+
+template <int IT, int JT>
+int launch(const mvit_gemm_tn_args& a, hipStream_t s) {
+  const long long nsteps = ((long long)a.M + 63) / 64;
+  int split = a.msplit > 0 ? a.msplit : 1;
+  if (split > nsteps) split = (int)nsteps;
+  dim3 grid((a.I + IT - 1) / IT, (a.J + JT - 1) / JT, split);
+  const size_t lds = 2 * (size_t)(IT / 64 + (JT + 63) / 64) * BLK_BYTES;
+  if (a.amode == MVIT_A_DENSE)
+    hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_DENSE>), grid, dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_CONV3>), grid, dim3(256), lds, s, a);
+  return MVIT_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!args) return MVIT_EINVAL;
+  const mvit_gemm_tn_args& a = *args;
+  if (a.M <= 0 || a.I <= 0 || a.J <= 0 || (a.I & 7) || (a.J & 7) || (a.ldb & 7)) return MVIT_EINVAL;
+  if (a.amode == MVIT_A_DENSE) {
+    if (a.lda & 7) return MVIT_EINVAL;
+  } else if (a.amode == MVIT_A_CONV3) {
+    if ((a.conv_C & 7) || (a.conv_ld & 7) || a.I != 9 * a.conv_C) return MVIT_EINVAL;
+  } else {
+    return MVIT_EINVAL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return a.J <= 32 ? launch<128, 32>(a, s) : launch<64, 128>(a, s);
+}

@@ -386,8 +386,7 @@ class HipEngine:
             w.dfeat = e(B, G, G, D)
             pix = [B * s1 * s1, B * s2 * s2, B * s3 * s3, B * s3 * s3, B * s2 * s2, B * s1 * s1, B * S * S]
             cinp = [8, 48, 96, _pad8(192 + D), _pad8(96 + 256), _pad8(48 + 128), _pad8(3 + 64)]
-            w.xcolT = e(max(9 * cp * m_ for cp, m_ in zip(cinp, pix)))
-            w.dyT = e(max(max(ch * m_ for ch, m_ in zip(chans, pix)), HEAD_C * B * S * S))
+            w.dyT = e(HEAD_C * B * S * S)
             wsz = [9 * cp * ch for cp, ch in zip(cinp, chans)] + [c.NH * 9 * HEAD_C]
             w.wscr = z(sum(wsz), dt=torch.float32)
             ow = [0]
@@ -545,17 +544,16 @@ class HipEngine:
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, w, i, src, r_in, cin_pad, ld, r_out, stride, dpre, cout):
-        """dW^T[(ky,kx,c), co] = sum_m Xcol^T[(ky,kx,c), m] * dY^T[co, m]  (split-K, f32 atomics)"""
+        """dW^T[(ky,kx,c), co] += sum_pixels im2col(X)[m, (ky,kx,c)] * dY[m, co]: TN MFMA GEMM, window gathered on the
+        fly from the NHWC input (no im2col / transposed copies), split over the pixel range."""
         B = w.B
         Mo = B * r_out * r_out
         K9 = 9 * cin_pad
-        xc = w.xcolT[:K9 * Mo].view(K9, Mo)
-        ops.im2col_t(src, xc, B, r_in, r_in, cin_pad, ld, r_out, r_out, stride)
-        dyT = w.dyT[:cout * Mo].view(cout, Mo)
-        ops.transpose_bf16(dpre, dyT, Mo, cout, cout, Mo)
-        tiles = ((K9 + 127) // 128) * max(1, (cout + 127) // 128)
-        ks = max(1, min(1024 // tiles, Mo // 512))
-        ops.gemm(xc, dyT, w.dWt[i], M=K9, N=cout, K=Mo, lda=Mo, ldb=Mo, ldc=cout, flags=OUT_F32 | ATOMIC, ksplit=ks)
+        it, jt = (128, 32) if cout <= 32 else (64, 128)
+        tiles = ((K9 + it - 1) // it) * ((cout + jt - 1) // jt)
+        ms = max(1, min(1024 // tiles, (Mo + 255) // 256))
+        ops.gemm_tn(src, dpre, w.dWt[i], M=Mo, I=K9, J=cout, ldb=cout, ldci=cout, msplit=ms,
+                    conv=(r_in, r_in, cin_pad, ld, r_out, r_out, stride))
 
     def backward(self, dY, on_decoder_done=None):
         """Gradients of every trainable parameter into the flat gradient buffer (views = param.grad)."""
@@ -654,6 +652,7 @@ class HipEngine:
         # ---- encoder (LoRA gradients; frozen weights need dgrad only)
         r_ = c.rank
         scale = c.Dh ** -0.5
+        lsplit = max(1, min(512 // ((D + 127) // 128), (M + 255) // 256))
         last = fz.blocks[c.L - 1]
         ops.layernorm_bwd(w.dtok, w.x_in[c.L], fz.nw, w.dx, last.ls2, w.dy, c.eps, accumulate=False)
         for l in range(c.L - 1, -1, -1):
@@ -669,11 +668,11 @@ class HipEngine:
             ops.skinny_xw(dq, pk.Bq16[l], w.dt, ldx=3 * D, ldo=2 * r_, M=M)                    # dt_q = dq @ (a B_q)^T
             ops.skinny_xw(dv, pk.Bv16[l], w.dt.view(-1)[r_:], ldx=3 * D, ldo=2 * r_, M=M)      # dt_v = dv @ (a B_v)^T
             t = w.t[l]
-            ops.skinny_xty(t, dq, fl.dBq[l], ldx=2 * r_, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
-            ops.skinny_xty(t.view(-1)[r_:], dv, fl.dBv[l], ldx=2 * r_, ldy=3 * D, osr=D, osn=1, M=M, N=D, R=r_)
-            # dA_q | dA_v in one pass over h1: rows 0..r-1 -> lora_q.A^T, rows r..2r-1 -> lora_v.A^T
-            ops.skinny_xty(w.dt, w.h1[l], fl.dAq[l], ldx=2 * r_, ldy=D, osb=fl.dAv[l].data_ptr() // 4 - fl.dAq[l].data_ptr() // 4,
-                           rgrp=r_, osr=1, osn=r_, M=M, N=D, R=2 * r_)
+            # LoRA weight gradients on the TN MFMA GEMM: dB = t^T dq (rows of B), dA = (dt^T h)^T (columns of A)
+            ops.gemm_tn(t, dq, fl.dBq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
+            ops.gemm_tn(t.view(-1)[r_:], dv, fl.dBv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
+            ops.gemm_tn(w.dt, w.h1[l], fl.dAq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
+            ops.gemm_tn(w.dt.view(-1)[r_:], w.h1[l], fl.dAv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
             if l > 0:
                 ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
                 ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)

@@ -95,6 +95,28 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     return c
 
 
+def gemm_tn(a, b, c, *, M, I, J, lda=None, ldb=None, ldci=None, ldcj=1, msplit=1, conv=None):
+    """C[i,j] (f32, += ) = sum_m A[m,i] * B[m,j]; conv=(H, W, C, ld, OH, OW, stride) makes A the virtual im2col."""
+    _chk_bf16(a, "A")
+    _chk_bf16(b, "B")
+    assert c.dtype == torch.float32
+    g = L.GemmTnArgs()
+    g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    g.M, g.I, g.J = M, I, J
+    g.ldb = ldb if ldb is not None else b.stride(0)
+    g.ldci = ldci if ldci is not None else c.stride(0)
+    g.ldcj = ldcj
+    g.msplit = msplit
+    if conv is None:
+        g.amode, g.lda = A_DENSE, lda if lda is not None else a.stride(0)
+    else:
+        g.amode = A_CONV3
+        g.conv_H, g.conv_W, g.conv_C, g.conv_ld, g.conv_OH, g.conv_OW, g.conv_stride = conv
+        g.lda = conv[3]
+    L.check(L.lib().mvit_gemm_tn_bf16(C.byref(g), _stream()), "mvit_gemm_tn_bf16")
+    return c
+
+
 def _call(name, *args):
     L.check(getattr(L.lib(), name)(*args, _stream()), name)
 

@@ -156,3 +156,40 @@ def test_conv3x3_fwd_stats_and_dgrad(B, H, W, C, Cout, stride):
     xg = xr.clone().requires_grad_(True)
     F.conv2d(xg, wr, stride=stride, padding=1).backward(dy.float().permute(0, 3, 1, 2))
     assert _rel(dx, xg.grad.permute(0, 2, 3, 1).reshape(-1, C)) < 1e-4
+
+
+@pytest.mark.parametrize("M,I,J", [(700, 16, 200), (5264, 8, 1536), (1000, 144, 32), (333, 72, 48)])
+def test_gemm_tn_dense(M, I, J):
+    ops = _ops()
+    a = _rand(M, I, seed=1).bfloat16()
+    b = _rand(M, J, seed=2).bfloat16()
+    ref = a.float().t() @ b.float()
+    c = torch.zeros(I, J, device="cuda")
+    ops.gemm_tn(a, b, c, M=M, I=I, J=J, msplit=1)
+    assert _rel(c, ref) < 1e-5
+    c2 = torch.ones(J, I, device="cuda")            # transposed output strides + accumulate onto existing values
+    ops.gemm_tn(a, b, c2, M=M, I=I, J=J, ldci=1, ldcj=I, msplit=5)
+    assert _rel(c2 - 1, ref.t()) < 1e-5
+    # column windows of wider matrices (LoRA slices)
+    aw = _rand(M, 16, seed=3).bfloat16()
+    bw = _rand(M, 3 * 104, seed=4).bfloat16()
+    c3 = torch.zeros(8, 104, device="cuda")
+    ops.gemm_tn(aw.view(-1)[8:], bw.view(-1)[2 * 104:], c3, M=M, I=8, J=104, lda=16, ldb=3 * 104, msplit=3)
+    assert _rel(c3, aw[:, 8:].float().t() @ bw[:, 208:].float()) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),
+                                                 (1, 24, 24, 72, 32, 1), (2, 8, 8, 1728, 256, 1)])
+def test_gemm_tn_conv_wgrad(B, H, W, C, Cout, stride):
+    ops = _ops()
+    x = _rand(B, H, W, C, seed=1).bfloat16()
+    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    M = B * OH * OW
+    dy = _rand(M, Cout, seed=2).bfloat16()
+    dwt = torch.zeros(9 * C, Cout, device="cuda")
+    ops.gemm_tn(x, dy, dwt, M=M, I=9 * C, J=Cout, msplit=3, conv=(H, W, C, C, OH, OW, stride))
+    w = torch.zeros(Cout, C, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), w, stride=stride, padding=1).backward(
+        dy.float().view(B, OH, OW, Cout).permute(0, 3, 1, 2))
+    ref = w.grad.permute(2, 3, 1, 0).reshape(9 * C, Cout)
+    assert _rel(dwt, ref) < 1e-5
