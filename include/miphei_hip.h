@@ -96,10 +96,6 @@ MVIT_API int mvit_layernorm_bwd(const void* dh_bf16, const float* x, const float
  * LoRALayer.forward x @ A (src/generators/lora.py:16-18) and its adjoint dq @ B^T. */
 MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void* out, int ldo, int M, int K, int R,
                             mvit_stream_t stream);
-/* out(f32)[(r/rgrp)*osb + (r%rgrp)*osr + n*osn] += sum_m X(bf16)[m,r] * Y(bf16)[m,n], R <= 16
- * (LoRA weight gradients dA = h^T dt, dB = t^T dq; rgrp/osb let one pass over Y fill the q and the v adapter). */
-MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, long long osb, int rgrp, int osr,
-                             int osn, int M, int N, int R, mvit_stream_t stream);
 /* NCHW f32 image -> bf16 patch matrix [B*g*g, Kp], k = c*p*p + iy*p + ix (timm PatchEmbed conv k=s=p). */
 MVIT_API int mvit_im2col_patch(const float* img, void* out_bf16, int B, int S, int p, int g, int Kp, mvit_stream_t stream);
 /* x[b,0]=cls, x[b,1..R]=reg  (timm _pos_embed with no_embed_class=True). */
@@ -149,12 +145,9 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
                                     const float* mean, const float* rstd, const float* gamma, const double* stats,
                                     float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
                                     mvit_stream_t stream);
-/* dst[c][r] = src[r][c] (bf16) and the transposed im2col out[(ky,kx,c)][m] of a 3x3/pad-1 window: the K-contiguous
- * operands of the weight-gradient GEMMs dW^T[k,co] = sum_m Xcol^T[k,m] dY^T[co,m]. */
+/* dst[c][r] = src[r][c] (bf16). */
 MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int ld_src, long long ld_dst,
                                  mvit_stream_t stream);
-MVIT_API int mvit_im2col_t(const void* x, void* out, int B, int H, int W, int C, int ld, int OH, int OW, int stride,
-                           mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- fused output heads (<=16 SegmentationHeads) */
 /* x = fusion output [M,32] bf16.  Stacked parameters: W1[NH,16,32], b1/gamma/beta/running_*[NH*16], W2[NH,16],

@@ -46,7 +46,6 @@ SIGNATURES = {
     "mvit_layernorm_fwd": [vp, vp, vp, vp, ci, ci, cf, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
     "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
-    "mvit_skinny_xty": [vp, ci, vp, ci, vp, ll, ci, ci, ci, ci, ci, ci, vp],
     "mvit_im2col_patch": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_prefix_tokens": [vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_cast_f32_bf16": [vp, vp, C.c_longlong, vp],
@@ -60,7 +59,6 @@ SIGNATURES = {
     "mvit_bn_relu_bwd_reduce": [vp, ci, vp, vp, vp, vp, vp, vp, ll, ci, ci, vp],
     "mvit_bn_relu_bwd_apply": [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, cd, vp],
     "mvit_transpose_bf16": [vp, vp, ci, ci, ci, ll, vp],
-    "mvit_im2col_t": [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_heads_moments": [vp, vp, ll, ci, vp],
     "mvit_heads_bn_from_moments": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cf, cf, ci, vp],
     "mvit_heads_gate_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp],

@@ -4,7 +4,7 @@
 //                          adjoints of both, with BatchNorm+ReLU optionally applied to the gathered source
 //                          and the result written straight into a channel slice of the concat buffer
 //   BatchNorm statistics finalisation / apply / backward (nn.BatchNorm2d in Basic_Conv3x3, mipheivit.py:33)
-//   transposes feeding the weight-gradient GEMMs.
+//   bf16 transpose (operand of the head-conv weight-gradient GEMM).
 #include "common.hpp"
 #include "../../include/miphei_hip.h"
 
@@ -246,32 +246,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
-// ------------------------------------------------------------------ transposed im2col: out[(tap,c)][m] for 3x3 pad 1
-__global__ __launch_bounds__(256) void im2col_t_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H,
-                                                       int W, int C, int ld, int OH, int OW, int stride, long long M) {
-  __shared__ bf16_t tile[64][66];
-  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
-  const int ky = tap / 3, kx = tap - ky * 3;
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const long long m = m0 + r;
-    bf16_t v = 0;
-    if (m < M && c0 + c < C) {
-      const int ox = (int)(m % OW);
-      const long long t = m / OW;
-      const int oy = (int)(t % OH), b = (int)(t / OH);
-      const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * H + iy) * W + ix) * ld + c0 + c];
-    }
-    tile[r][c] = v;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int c = i >> 6, r = i & 63;
-    if (m0 + r < M && c0 + c < C) out[((size_t)tap * C + c0 + c) * M + m0 + r] = tile[r][c];
-  }
-}
-
 inline int nblk(long long work, int per, int cap = 16384) {
   long long b = (work + per - 1) / per;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -351,16 +325,6 @@ MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int 
   if (R <= 0 || Cc <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(transpose_kernel, dim3((R + 63) / 64, (Cc + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, (bf16_t*)dst, R, Cc, ld_src, ld_dst);
-  return MVIT_LAUNCH_CHECK();
-}
-
-MVIT_API int mvit_im2col_t(const void* x, void* out, int B, int H, int W, int C, int ld, int OH, int OW, int stride,
-                           mvit_stream_t stream) {
-  MVIT_CLEAR_ERROR();
-  if (B <= 0 || C <= 0 || stride <= 0) return MVIT_EINVAL;
-  const long long M = (long long)B * OH * OW;
-  hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((M + 63) / 64), (C + 63) / 64, 9), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (bf16_t*)out, B, H, W, C, ld, OH, OW, stride, M);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -170,74 +170,6 @@ __global__ __launch_bounds__(64) void skinny_xw_kernel(const bf16_t* __restrict_
   }
 }
 
-// ------------------------------------------------------------------ out[r,n] += sum_m X[m,r] * Y[m,n], R <= 16
-// HBM-bound on Y: each lane owns 4 consecutive columns (8-byte loads), the 4 waves of a block split the rows of a
-// 128-row chunk, X rows are broadcast from LDS; partial sums meet in LDS, then one f32 atomic per output.
-// Output element (r, n) lives at out[(r / rgrp) * osb + (r % rgrp) * osr + n * osn]  (two LoRA matrices in one pass).
-constexpr int XTY_ROWS = 256;   // rows per block (8 waves x 32 rows)
-__global__ __launch_bounds__(512) void skinny_xty_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y,
-                                                         int ldy, float* __restrict__ out, long long osb, int rgrp, int osr,
-                                                         int osn, int M, int N, int R) {
-  __shared__ __attribute__((aligned(16))) float xs[XTY_ROWS][16];
-  __shared__ float red[16][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * 256 + lane * 4;
-  const int mbeg = blockIdx.y * XTY_ROWS;
-  for (int i = threadIdx.x; i < XTY_ROWS * 16; i += 512) {
-    const int m = mbeg + (i >> 4), r = i & 15;
-    xs[i >> 4][r] = (m < M && r < R) ? bf2f(X[(size_t)m * ldx + r]) : 0.f;
-  }
-  for (int i = threadIdx.x; i < 16 * 256; i += 512) (&red[0][0])[i] = 0.f;
-  __syncthreads();
-  float acc[16][4];
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[r][q] = 0.f;
-  const bool full = n0 + 3 < N;
-  if (n0 < N) {
-    // rows wave, wave+8, ...: 8 row loads in flight per lane (rows past M are clamped; their X rows are zero in LDS)
-    constexpr int UN = 8;
-    for (int i0 = wave; i0 < XTY_ROWS; i0 += 8 * UN) {
-      float y[UN][4];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int m = min(mbeg + i0 + 8 * u, M - 1);
-        if (full) {
-          const uint2 t = *(const uint2*)(Y + (size_t)m * ldy + n0);
-          y[u][0] = __uint_as_float(t.x << 16), y[u][1] = __uint_as_float(t.x & 0xffff0000u);
-          y[u][2] = __uint_as_float(t.y << 16), y[u][3] = __uint_as_float(t.y & 0xffff0000u);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) y[u][q] = n0 + q < N ? bf2f(Y[(size_t)m * ldy + n0 + q]) : 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const float4* xr = (const float4*)xs[i0 + 8 * u];
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const float4 xv = xr[r4];
-          const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r4 * 4 + k][q] += xx[k] * y[u][q];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) atomicAdd(&red[r][lane * 4 + q], acc[r][q]);  // 8 waves meet in LDS
-  __syncthreads();
-  for (int e = threadIdx.x; e < R * 256; e += 512) {
-    const int r = e >> 8, c = e & 255, n = blockIdx.x * 256 + c;
-    if (n < N) atomicAdd(out + (size_t)(r / rgrp) * osb + (size_t)(r % rgrp) * osr + (size_t)n * osn, red[r][c]);
-  }
-}
-
 // ------------------------------------------------------------------ patch gather: NCHW f32 image -> [B*g*g, Kp] bf16
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B,
                                                            int S, int p, int g, int Kp) {
@@ -326,15 +258,6 @@ MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void
   if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7) || (ldw & 7)) return MVIT_EINVAL;
   hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
                      (const bf16_t*)W, ldw, (bf16_t*)out, ldo, M, K, R);
-  return MVIT_LAUNCH_CHECK();
-}
-
-MVIT_API int mvit_skinny_xty(const void* X, int ldx, const void* Y, int ldy, float* out, long long osb, int rgrp, int osr,
-                             int osn, int M, int N, int R, mvit_stream_t stream) {
-  MVIT_CLEAR_ERROR();
-  if (M <= 0 || N <= 0 || R <= 0 || R > 16 || rgrp <= 0 || (ldy & 3)) return MVIT_EINVAL;
-  hipLaunchKernelGGL(skinny_xty_kernel, dim3((N + 255) / 256, (M + XTY_ROWS - 1) / XTY_ROWS), dim3(512), 0,
-                     (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, out, osb, rgrp, osr, osn, M, N, R);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -141,14 +141,6 @@ def skinny_xw(X, W, out, *, ldx=None, ldw=None, ldo=None, M=None, K=None, R=None
     return out
 
 
-def skinny_xty(X, Y, out, *, ldx=None, ldy=None, osr=None, osn=None, M=None, N=None, R=None, osb=0, rgrp=None):
-    R = R or X.shape[1]
-    _call("mvit_skinny_xty", _p(X), ldx or X.stride(0), _p(Y), ldy or Y.stride(0), _p(out), osb, rgrp or R,
-          osr if osr is not None else out.stride(0), osn if osn is not None else out.stride(1), M or X.shape[0],
-          N or Y.shape[1], R)
-    return out
-
-
 def im2col_patch(img, out, patch, grid):
     B, _, S, _ = img.shape
     _call("mvit_im2col_patch", _p(img), _p(out), B, S, patch, grid, out.shape[1])
@@ -212,10 +204,6 @@ def bn_relu_bwd(dy, ld_dy, x, scale, shift, mean, rstd, gamma, stats, dgamma, db
 
 def transpose_bf16(src, dst, R, Cc, ld_src, ld_dst):
     _call("mvit_transpose_bf16", _p(src), _p(dst), R, Cc, ld_src, ld_dst)
-
-
-def im2col_t(x, out, B, H, W, C_, ld, OH, OW, stride):
-    _call("mvit_im2col_t", _p(x), _p(out), B, H, W, C_, ld, OH, OW, stride)
 
 
 def heads_moments(x, mom, M, nslots):

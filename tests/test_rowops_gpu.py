@@ -59,23 +59,6 @@ def test_skinny():
     out2 = torch.zeros(M, 16, device="cuda", dtype=torch.bfloat16)
     ops.skinny_xw(Xw.view(-1)[2 * 104:], Bm, out2.view(-1)[8:], ldx=3 * 104, ldo=16, M=M)
     assert _rel(out2[:, 8:].float(), Xw[:, 208:].float() @ Bm.float().t()) < 4e-3 and float(out2[:, :8].abs().max()) == 0
-    # X^T Y
-    T = _rand(M, 16, seed=4).bfloat16()
-    Y = _rand(M, 200, seed=5).bfloat16()
-    acc = torch.zeros(8, 200, device="cuda")
-    ops.skinny_xty(T[:, 8:], Y, acc, ldx=16, R=8)
-    assert _rel(acc, T[:, 8:].float().t() @ Y.float()) < 1e-5
-    accT = torch.zeros(200, 8, device="cuda")
-    ops.skinny_xty(T, Y, accT, osr=1, osn=8, R=8)
-    assert _rel(accT, Y.float().t() @ T[:, :8].float()) < 1e-5
-    # both halves in one pass, each to its own [200, 8] matrix
-    two = torch.zeros(2, 200, 8, device="cuda")
-    ops.skinny_xty(T, Y, two, osb=200 * 8, rgrp=8, osr=1, osn=8, R=16)
-    assert _rel(two[0], Y.float().t() @ T[:, :8].float()) < 1e-5 and _rel(two[1], Y.float().t() @ T[:, 8:].float()) < 1e-5
-    Y2 = torch.randn(M, 1000, device="cuda").bfloat16()[:, :998]
-    acc2 = torch.zeros(16, 998, device="cuda")
-    ops.skinny_xty(T, Y2, acc2, ldy=1000, R=16)
-    assert _rel(acc2, T.float().t() @ Y2.float()) < 1e-5
 
 
 def test_patch_prefix_cast():
