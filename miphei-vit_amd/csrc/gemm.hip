@@ -4,6 +4,18 @@
 
 static int dispatch(const mvit_gemm_args& a, hipStream_t s);
 
+namespace mvit_gemm {
+int gemm_num_cus() {
+  static const int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+      cu = 256;
+    return cu;
+  }();
+  return n;
+}
+}  // namespace mvit_gemm
+
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   using namespace mvit_gemm;

@@ -2,14 +2,22 @@
 //
 //   C[M,N] = A[M,K] * B[N,K]^T (+ A2 * B2^T)      f32 accumulate on v_mfma_f32_32x32x16_bf16
 //
-// Structure: 256 threads = 4 wavefronts (64 lanes each), BMxBNx64 block tile, operands staged
-// global -> registers -> LDS (issue loads for tile t+1 before the MFMAs of tile t, write them after:
-// HBM latency hides under the matrix pipe), two LDS buffers, one barrier per K-step.  LDS rows are
-// 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row>>1)&7 so that every
-// ds_read_b128 lane group touches 16 distinct 16-byte slots (conflict-free, MI355X LDS banking).
-// The A operand loader is either dense or a 3x3 window gather from an NHWC activation (implicit GEMM
-// convolution, forward and adjoint), so the decoder convolutions run on the same mainloop.
-// Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles.
+// Structure
+//  * 4 or 8 wavefronts (64 lanes), each owning a 64x64 / 32x32 / 64x32 sub-tile of a BMxBN block tile, BK = 64.
+//  * Operands go global -> LDS by DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip).  LDS rows are 128 B
+//    (64 bf16); the 16-byte chunk index is XOR-swizzled with (row>>1)&7 ON THE SOURCE ADDRESS so every ds_read_b128
+//    lane group touches 16 distinct slots (conflict-free).  M / K tails and the zero padding of the 3x3 window come
+//    from out-of-range offsets (hardware returns 0).
+//  * NSTAGE LDS buffers with NSTAGE-1 K tiles of DMA in flight: counted s_waitcnt vmcnt + raw s_barrier, never a
+//    __syncthreads() inside the K loop (it would drain the DMA queue).
+//  * Persistent blocks: a block walks tiles blockIdx.x, +gridDim.x, ...; before running the epilogue of tile i it has
+//    already issued the first NSTAGE-1 K tiles of tile i+1, so launch, descriptor setup and first-tile DMA latency
+//    are paid once per block, not once per tile.  Tile order is XCD-aware and grouped (GROUP_M tile rows x all
+//    columns) so the ~32 blocks sharing one XCD's 4 MiB L2 reuse each other's A / B panels.
+//  * Epilogue: 16-row accumulator slabs go through a wave-private f32 LDS panel (inside the LDS buffer consumed
+//    last) and leave as 16-byte stores (8 consecutive columns per lane).
+// The A operand loader is dense or a 3x3 window gather from an NHWC activation (implicit-GEMM convolution forward
+// and adjoint), so the decoder convolutions run on the same mainloop.
 #pragma once
 #include <type_traits>
 #include "common.hpp"
@@ -24,12 +32,18 @@ struct ConvRow {
   bool ok;
 };
 
-// number of LDS stages: the 8-wave 256x128 tile runs one block per CU and keeps two K tiles of DMA in flight
+// LDS stages: the 8-wave 256x128 tile runs one block per CU and keeps two K tiles of DMA in flight
 constexpr int gemm_stages(int bm, int bn) { return (bm + bn) * 128 * 3 <= 160 * 1024 && bm >= 256 ? 3 : 2; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+constexpr size_t gemm_lds_bytes() {
+  return (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit_gemm_args p) {
-  constexpr int NT = 64 * WAVES_M * WAVES_N;  // threads
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int NT = 64 * NW;                 // threads
   constexpr int RPI = NT / 8;                 // tile rows filled per DMA instruction of the block
   constexpr int NSTAGE = gemm_stages(BM, BN);
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -37,32 +51,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr int A_CH = BM / RPI, B_CH = BN / RPI;
   constexpr int LPT = A_CH + B_CH;            // DMA instructions per thread per K tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int SLD = WTN + 4;                // epilogue panel row stride (floats)
+  constexpr int SLAB = 16 * SLD;              // 16-row slab per wave
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+  static_assert((size_t)NW * SLAB * 4 + (size_t)WAVES_M * BN * 8 <= (size_t)BUF_BYTES, "epilogue panel must fit one LDS buffer");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int frag_row = lane & 31, frag_half = lane >> 5;
+  const int c8 = tid & 7;         // 16-byte slot inside the 64-wide K slice
+  const int row_base = tid >> 3;  // 0..RPI-1, +RPI per chunk index
+  const int c8s = c8 ^ ((row_base >> 1) & 7);  // source chunk for this lane's LDS slot (same for every +RPI row)
+  constexpr unsigned OOB = 0x80000000u;
 
-  // ---- XCD-aware tile mapping (bijective for any grid size)
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int nwg = gridDim.x;
-  int wg;
-  {
-    const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  // grouped order: GROUP_M tile rows x all tile columns at a time, so the ~32 blocks resident on one XCD share few
-  // A / B panels per K step and its 4 MiB L2 serves most of the operand DMA
-  constexpr int GROUP_M = BM >= 256 ? 4 : 8;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int per_group = GROUP_M * tiles_n;
-  const int first_m = (wg / per_group) * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tile_m = first_m + (wg % per_group) % gsz, tile_n = (wg % per_group) / gsz;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
 
-  // ---- K range (split-K over blockIdx.z)
+  // ---- K range (split-K over blockIdx.z), identical for every tile
   const int nk1 = (p.K + BK - 1) / BK;
   const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
   const int nk = nk1 + nk2;
@@ -79,30 +88,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   const bf16_t* __restrict__ A2p = (const bf16_t*)p.A2;
   const bf16_t* __restrict__ B2p = (const bf16_t*)p.B2;
 
-  const int c8 = tid & 7;       // 16-byte chunk inside the 64-wide K slice
-  const int row_base = tid >> 3;  // 0..RPI-1, +RPI per chunk index
-
-  ConvRow crow[A_CH];
-  if (AMODE != MVIT_A_DENSE) {
-#pragma unroll
-    for (int j = 0; j < A_CH; ++j) {
-      const int gm = m0 + row_base + RPI * j;
-      crow[j].ok = gm < p.M;
-      const int g = crow[j].ok ? gm : 0;
-      crow[j].x = g % p.conv_OW;
-      const int t = g / p.conv_OW;
-      crow[j].y = t % p.conv_OH;
-      crow[j].b = t / p.conv_OH;
-    }
-  }
-
-  // ---- operand staging: global -> LDS directly (buffer_load ... lds, 16 B per lane, no VGPR round trip).
-  // One wave instruction fills 8 consecutive 128-byte LDS rows (lane l -> row l>>3, 16-byte slot l&7); the XOR
-  // swizzle lives on the SOURCE side: slot s of row r receives global chunk s ^ ((r>>1)&7).  Out-of-range rows,
-  // the K tail and the zero padding of the convolution window use an out-of-bounds offset (hardware returns 0).
-  constexpr unsigned OOB = 0x80000000u;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int c8s = c8 ^ ((row_base >> 1) & 7);  // source chunk for this lane's LDS slot (same for every +RPI row)
   auto make_rsrc = [](const bf16_t* ptr) {
     // wave-uniform by construction (kernel arguments + blockIdx arithmetic); readfirstlane makes it provable so the
     // descriptor stays in SGPRs and hipcc does not wrap every buffer_load in a waterfall loop
@@ -110,14 +95,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc((AMODE == MVIT_A_DENSE) ? Ap + (size_t)m0 * p.lda : Ap);
-  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(Bp + (size_t)n0 * p.ldb);
-  const __amdgpu_buffer_rsrc_t rsA2 = make_rsrc(A2p ? A2p + (size_t)m0 * p.lda2 : Ap);
-  const __amdgpu_buffer_rsrc_t rsB2 = make_rsrc(B2p ? B2p + (size_t)n0 * p.ldb2 : Bp);
 
+  // ---- per-tile context
+  int m0 = 0, n0 = 0;
+  __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2;
+  ConvRow crow[A_CH];
+
+  auto setup_tile = [&](int vt) {
+    // virtual tile id -> XCD-aware, grouped tile coordinates (bijective for any tile count):
+    // block b runs on XCD b%8, so ids congruent mod 8 form one XCD's contiguous chunk of the grouped order
+    int wg;
+    {
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = vt & 7;
+      wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
+    }
+    constexpr int GROUP_M = BM >= 256 ? 4 : 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (wg / per_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (wg % per_group) % gsz, tile_n = (wg % per_group) / gsz;
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
+    rsA = make_rsrc((AMODE == MVIT_A_DENSE) ? Ap + (size_t)m0 * p.lda : Ap);
+    rsB = make_rsrc(Bp + (size_t)n0 * p.ldb);
+    rsA2 = make_rsrc(A2p ? A2p + (size_t)m0 * p.lda2 : Ap);
+    rsB2 = make_rsrc(B2p ? B2p + (size_t)n0 * p.ldb2 : Bp);
+    if (AMODE != MVIT_A_DENSE) {
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        const int gm = m0 + row_base + RPI * j;
+        crow[j].ok = gm < p.M;
+        const int g = crow[j].ok ? gm : 0;
+        crow[j].x = g % p.conv_OW;
+        const int t = g / p.conv_OW;
+        crow[j].y = t % p.conv_OH;
+        crow[j].b = t / p.conv_OH;
+      }
+    }
+  };
+
+  // ---- operand staging: one K tile (A: BM x 64, B: BN x 64) by DMA into LDS buffer `buf`
   auto issue_tile_impl = [&](int t, int buf, auto ext_tag) {
     constexpr bool ext = decltype(ext_tag)::value;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
     char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
     char* b = a + A_BYTES;
     const int k0 = (ext ? t - nk1 : t) * BK + c8s * 8;
@@ -176,290 +195,314 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       }
     }
   };
-
   auto issue_tile = [&](int t, int buf) {
     if (t < nk1)
       issue_tile_impl(t, buf, std::false_type{});
     else
       issue_tile_impl(t, buf, std::true_type{});
   };
-
-  f32x16 acc[TM][TN];
+  auto issue_prologue = [&](int first_buf) {
+    int b = first_buf;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int frag_row = lane & 31, frag_half = lane >> 5;
-
-  // ---- main loop: NSTAGE LDS buffers, NSTAGE-1 K tiles of DMA in flight.  Only counted vmcnt waits and a raw
-  // s_barrier (a __syncthreads() would drain the whole DMA queue): tile t is waited for by the waves that issued
-  // it, the barrier publishes it and also proves every wave is done reading the buffer refilled next.
-#pragma unroll
-  for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
-    if (t_begin + s_ < t_end) issue_tile(t_begin + s_, s_);
-  int cur = 0, nxt = NSTAGE - 1;
-  if (p.flags & 0x1000) t_end = t_begin;  // debug: no main loop
-  for (int t = t_begin; t < t_end; ++t) {
-    if (NSTAGE == 3 && t + 1 < t_end)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + NSTAGE - 1 < t_end && !(p.flags & 0x100)) issue_tile(t + NSTAGE - 1, nxt);
-    if (p.flags & 0x200) { cur = cur + 1 == NSTAGE ? 0 : cur + 1; nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1; continue; }
-    const char* a = smem + cur * BUF_BYTES;
-    const char* b = a + A_BYTES;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 fa[TM], fb[TN];
-      const int ch = s * 2 + frag_half;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wave_m * WTM + i * 32 + frag_row;
-        fa[i] = *(const bf16x8*)(a + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wave_n * WTN + j * 32 + frag_row;
-        fb[j] = *(const bf16x8*)(b + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    for (int s_ = 0; s_ < NSTAGE - 1; ++s_) {
+      if (t_begin + s_ < t_end) issue_tile(t_begin + s_, b);
+      b = b + 1 == NSTAGE ? 0 : b + 1;
     }
-    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
-  }
-  __syncthreads();  // LDS is reused by the statistics epilogue
-
-  // ------------------------------------------------------------------ epilogue
-  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane owns single columns,
-  // so direct stores would be 2-byte scatters.  Instead every wave parks its accumulators in a private f32 LDS
-  // panel, re-reads them row-wise (4 consecutive columns per lane), applies the epilogue on float4s and stores
-  // 8-byte (bf16) / 16-byte (f32) pieces: 16 (or 8) lanes cover one contiguous row segment of the output.
-  constexpr int SLD = WTN + 4;                                    // panel row stride in floats (16-byte aligned)
-  constexpr int V = 8;                                            // columns per lane: 16-byte bf16 stores
-  constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 32 / V : WTN / V;  // lanes per output row
-  constexpr int RPP = 64 / CPR;                                   // rows per pass
-  constexpr int PANEL = WTM * SLD;
-  if (p.flags & 0x800) return;  // debug: no epilogue
-  float* stg = (float*)smem + (size_t)wave * PANEL;
-  const int col_l = lane & 31;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_half) * SLD + j * 32 + col_l] = acc[i][j][r];
+  };
 
   const bool out_f32 = p.flags & MVIT_OUT_F32;
   const bool atomic = p.flags & MVIT_ATOMIC;
   const bool scalar_io = p.flags & 0x400;  // set by the dispatcher when a pointer / leading dimension is not vector-aligned
   float* Cf = (float*)p.C;
   bf16_t* Cb = (bf16_t*)p.C;
-  const int lr = lane / CPR, lc = (lane % CPR) * V;
-  const int colw = n0 + wave_n * WTN;  // first column of this wave's panel
 
-  auto ld8bf = [&](const bf16_t* q, float (&o)[V], int nv) {
-    if (nv == V && !scalar_io) {
-      const uint4 t = *(const uint4*)q;
-      const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+  int vt = blockIdx.x;
+  setup_tile(vt);
+  int cb = 0;  // LDS buffer holding the first K tile of the current output tile
+  issue_prologue(cb);
+
+  for (;;) {
+    f32x16 acc[TM][TN];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
-    } else {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < V; ++e) o[e] = e < nv ? bf2f(q[e]) : 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---------------------------------------------------------------- main loop
+    int ib = cb + NSTAGE - 1 >= NSTAGE ? cb - 1 : cb + NSTAGE - 1;  // buffer receiving K tile t + NSTAGE - 1
+    for (int t = t_begin; t < t_end; ++t) {
+      if (NSTAGE == 3 && t + 1 < t_end)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + NSTAGE - 1 < t_end) issue_tile(t + NSTAGE - 1, ib);
+      const char* a = smem + cb * BUF_BYTES;
+      const char* b = a + A_BYTES;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 fa[TM], fb[TN];
+        const int ch = s * 2 + frag_half;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wave_m * WTM + i * 32 + frag_row;
+          fa[i] = *(const bf16x8*)(a + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wave_n * WTN + j * 32 + frag_row;
+          fb[j] = *(const bf16x8*)(b + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      cb = cb + 1 == NSTAGE ? 0 : cb + 1;
+      ib = ib + 1 == NSTAGE ? 0 : ib + 1;
     }
-  };
-  auto st8bf = [&](bf16_t* q, const float (&o)[V], int nv) {
-    if (nv == V && !scalar_io) {
-      uint4 t;
-      t.x = pack2bf(o[0], o[1]), t.y = pack2bf(o[2], o[3]), t.z = pack2bf(o[4], o[5]), t.w = pack2bf(o[6], o[7]);
-      *(uint4*)q = t;
-    } else {
-      for (int e = 0; e < nv; ++e) q[e] = f2bf(o[e]);
+    // every wave is done reading the last K tile: its buffer becomes the epilogue panel, the other NSTAGE-1
+    // buffers (starting at cb) receive the first K tiles of the next output tile while the epilogue runs
+    __builtin_amdgcn_s_barrier();
+    const int last = cb == 0 ? NSTAGE - 1 : cb - 1;
+    const int em0 = m0, en0 = n0;
+    const int vt_next = vt + gridDim.x;
+    const bool has_next = vt_next < ntiles;
+    if (has_next) {
+      setup_tile(vt_next);
+      issue_prologue(cb);
     }
-  };
-  auto ld8f = [&](const float* q, float (&o)[V], int nv) {
-    if (nv == V && !scalar_io) {
-      const float4 t0 = ((const float4*)q)[0], t1 = ((const float4*)q)[1];
+
+    // ---------------------------------------------------------------- epilogue of tile (em0, en0)
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  16-row slabs of the wave's
+    // sub-tile are parked in a wave-private f32 panel and re-read row-wise: each lane applies the epilogue to 8
+    // consecutive columns of one row and issues 16-byte stores; CPR lanes cover one contiguous row segment.
+    constexpr int V = 8;
+    constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 32 / V : WTN / V;  // lanes per output row
+    constexpr int RPP = 64 / CPR;                                      // rows per pass
+    constexpr int NPASS = RPP >= 16 ? 1 : 16 / RPP;
+    float* stg = (float*)(smem + last * BUF_BYTES) + (size_t)wave * SLAB;
+    const int col_l = lane & 31;
+    const int lr = lane / CPR, lc = (lane % CPR) * V;
+    const int colw = en0 + wave_n * WTN;  // first column of this wave's panel
+
+    auto ld8bf = [&](const bf16_t* q, float (&o)[V], int nv) {
+      if (nv == V && !scalar_io) {
+        const uint4 t = *(const uint4*)q;
+        const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = e < nv ? bf2f(q[e]) : 0.f;
+      }
+    };
+    auto st8bf = [&](bf16_t* q, const float (&o)[V], int nv) {
+      if (nv == V && !scalar_io) {
+        uint4 t;
+        t.x = pack2bf(o[0], o[1]), t.y = pack2bf(o[2], o[3]), t.z = pack2bf(o[4], o[5]), t.w = pack2bf(o[6], o[7]);
+        *(uint4*)q = t;
+      } else {
+        for (int e = 0; e < nv; ++e) q[e] = f2bf(o[e]);
+      }
+    };
+    auto ld8f = [&](const float* q, float (&o)[V], int nv) {
+      if (nv == V && !scalar_io) {
+        const float4 t0 = ((const float4*)q)[0], t1 = ((const float4*)q)[1];
+        o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = e < nv ? q[e] : 0.f;
+      }
+    };
+    auto st8f = [&](float* q, const float (&o)[V], int nv) {
+      if (nv == V && !scalar_io) {
+        ((float4*)q)[0] = make_float4(o[0], o[1], o[2], o[3]);
+        ((float4*)q)[1] = make_float4(o[4], o[5], o[6], o[7]);
+      } else {
+        for (int e = 0; e < nv; ++e) q[e] = o[e];
+      }
+    };
+    auto panel8 = [&](int rl, int c0, float (&o)[V]) {
+      const float4 t0 = *(const float4*)(stg + rl * SLD + c0), t1 = *(const float4*)(stg + rl * SLD + c0 + 4);
       o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < V; ++e) o[e] = e < nv ? q[e] : 0.f;
-    }
-  };
-  auto st8f = [&](float* q, const float (&o)[V], int nv) {
-    if (nv == V && !scalar_io) {
-      ((float4*)q)[0] = make_float4(o[0], o[1], o[2], o[3]);
-      ((float4*)q)[1] = make_float4(o[4], o[5], o[6], o[7]);
-    } else {
-      for (int e = 0; e < nv; ++e) q[e] = o[e];
-    }
-  };
-  auto panel8 = [&](int rl, int c0, float (&o)[V]) {
-    const float4 t0 = *(const float4*)(stg + rl * SLD + c0), t1 = *(const float4*)(stg + rl * SLD + c0 + 4);
-    o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
-  };
+    };
 
-  float st_s[V], st_q[V];
+    float st_s[V], st_q[V];
 #pragma unroll
-  for (int e = 0; e < V; ++e) st_s[e] = st_q[e] = 0.f;
+    for (int e = 0; e < V; ++e) st_s[e] = st_q[e] = 0.f;
 
-  if constexpr (EPI == MVIT_EPI_SWIGLU) {
-    bf16_t* aux = (bf16_t*)p.aux;
-    const int ca = colw + lc, cb = ca + 32, cg = (colw >> 1) + lc;
-    float bia[V], bib[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) bia[e] = p.bias ? p.bias[ca + e] : 0.f, bib[e] = p.bias ? p.bias[cb + e] : 0.f;
-#pragma unroll
-    for (int it = 0; it < WTM / RPP; ++it) {
-      const int rl = it * RPP + lr, row = m0 + wave_m * WTM + rl;
-      float a_[V], b_[V], g_[V];
-      panel8(rl, lc, a_);
-      panel8(rl, lc + 32, b_);
-      if (row >= p.M) continue;
-#pragma unroll
-      for (int e = 0; e < V; ++e) a_[e] += bia[e], b_[e] += bib[e];
-      if (aux) {
-        st8bf(aux + (size_t)row * p.ldaux + ca, a_, V);
-        st8bf(aux + (size_t)row * p.ldaux + cb, b_, V);
-      }
-#pragma unroll
-      for (int e = 0; e < V; ++e) g_[e] = a_[e] * sigmoidf_(a_[e]) * b_[e];
-      st8bf(Cb + (size_t)row * p.ldc + cg, g_, V);
-    }
-  } else {
+    // column-dependent epilogue constants
     const int col = colw + lc;
-    const int nv = min(V, p.N - col);  // valid columns of this lane's group (<= 0: none)
-    float bias[V], gam[V];
+    const int nv = (EPI == MVIT_EPI_SWIGLU) ? V : min(V, p.N - col);  // valid columns of this lane's group
+    float bias[V], gam[V], bias2[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      bias[e] = (p.bias && e < nv) ? p.bias[col + e] : 0.f;
-      gam[e] = (p.gamma && e < nv) ? p.gamma[col + e] : 1.f;
-    }
-#pragma unroll
-    for (int it = 0; it < WTM / RPP; ++it) {
-      const int rl = it * RPP + lr, row = m0 + wave_m * WTM + rl;
-      float v[V];
-      panel8(rl, lc, v);
-      if (row >= p.M || nv <= 0) continue;
-#pragma unroll
-      for (int e = 0; e < V; ++e) v[e] += bias[e];
-      if constexpr (EPI == MVIT_EPI_STORE) {
-        const size_t o = (size_t)row * p.ldc + col;
-        if (atomic) {
-          for (int e = 0; e < nv; ++e) atomicAdd(Cf + o + e, v[e]);
-        } else if (out_f32) {
-          st8f(Cf + o, v, nv);
-        } else {
-          if (p.flags & MVIT_ACCUM_BF16) {
-            float old[V];
-            ld8bf(Cb + o, old, nv);
-#pragma unroll
-            for (int e = 0; e < V; ++e) v[e] += old[e];
-          }
-          st8bf(Cb + o, v, nv);
-        }
-      } else if constexpr (EPI == MVIT_EPI_GELU) {
-        if (p.aux) st8bf((bf16_t*)p.aux + (size_t)row * p.ldaux + col, v, nv);
-        float g_[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) g_[e] = gelu_erf(v[e]);
-        st8bf(Cb + (size_t)row * p.ldc + col, g_, nv);
-      } else if constexpr (EPI == MVIT_EPI_RESID) {
-        const size_t o = (size_t)row * p.ldc + col;
-        float r_[V];
-        ld8f(p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o, r_, nv);
-#pragma unroll
-        for (int e = 0; e < V; ++e) r_[e] += gam[e] * v[e];
-        st8f(Cf + o, r_, nv);
-      } else if constexpr (EPI == MVIT_EPI_PATCH) {
-        const int img = row / p.patch_P, pp = row - img * p.patch_P;
-        const size_t o = (size_t)(img * p.patch_ntok + p.patch_prefix + pp) * p.ldc + col;
-        for (int e = 0; e < nv; ++e) Cf[o + e] = v[e] + p.pos[(size_t)pp * p.N + col + e];
-      } else if constexpr (EPI == MVIT_EPI_STATS) {
-        st8bf(Cb + (size_t)row * p.ldc + col, v, nv);
-#pragma unroll
-        for (int e = 0; e < V; ++e)
-          if (e < nv) st_s[e] += v[e], st_q[e] += v[e] * v[e];
-      } else if constexpr (EPI == MVIT_EPI_DSWIGLU) {
-        // gate columns col..col+7 live at packed positions ca.. (a) and ca+32.. (b) of the saved pre-activation
-        const bf16_t* u = (const bf16_t*)p.aux;
-        const int ca = ((col >> 5) << 6) + (col & 31);
-        float a_[V], b_[V], da[V], db[V];
-        ld8bf(u + (size_t)row * p.ldaux + ca, a_, nv);
-        ld8bf(u + (size_t)row * p.ldaux + ca + 32, b_, nv);
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const float sg = sigmoidf_(a_[e]);
-          da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
-          db[e] = v[e] * a_[e] * sg;
-        }
-        st8bf(Cb + (size_t)row * p.ldc + ca, da, nv);
-        st8bf(Cb + (size_t)row * p.ldc + ca + 32, db, nv);
-      } else if constexpr (EPI == MVIT_EPI_DGELU) {
-        float u_[V], o_[V];
-        ld8bf((const bf16_t*)p.aux + (size_t)row * p.ldaux + col, u_, nv);
-#pragma unroll
-        for (int e = 0; e < V; ++e) o_[e] = v[e] * gelu_erf_grad(u_[e]);
-        st8bf(Cb + (size_t)row * p.ldc + col, o_, nv);
+      if constexpr (EPI == MVIT_EPI_SWIGLU) {
+        bias[e] = p.bias ? p.bias[col + e] : 0.f;
+        bias2[e] = p.bias ? p.bias[col + 32 + e] : 0.f;
+        gam[e] = 1.f;
+      } else {
+        bias[e] = (p.bias && e < nv) ? p.bias[col + e] : 0.f;
+        gam[e] = (p.gamma && e < nv) ? p.gamma[col + e] : 1.f;
+        bias2[e] = 0.f;
       }
     }
-  }
 
-  if constexpr (EPI == MVIT_EPI_STATS) {
-    // lanes with equal lane % CPR own the same V columns; then across the WAVES_M waves through LDS
-    float* red = (float*)smem + (size_t)(WAVES_M * WAVES_N) * PANEL;  // [WAVES_M][BN][2], behind the staging panels
+    if (!(p.flags & 0x800)) {  // (0x800: debug, no epilogue)
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int o = CPR; o < 64; o <<= 1) {
-        st_s[e] += __shfl_xor(st_s[e], o, 64);
-        st_q[e] += __shfl_xor(st_q[e], o, 64);
-      }
+        for (int g = 0; g < 2; ++g) {
+          // park rows 32*i + 16*g .. +15 of the wave's sub-tile (accumulator registers 8g .. 8g+7)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8)
+              stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * frag_half) * SLD + j * 32 + col_l] = acc[i][j][8 * g + r8];
+#pragma unroll
+          for (int it = 0; it < NPASS; ++it) {
+            const int rl = it * RPP + lr;  // row inside the slab
+            if (RPP > 16 && rl >= 16) continue;
+            const int row = em0 + wave_m * WTM + i * 32 + 16 * g + rl;
+            if constexpr (EPI == MVIT_EPI_SWIGLU) {
+              bf16_t* aux = (bf16_t*)p.aux;
+              const int ca = col, cbb = col + 32, cg = (colw >> 1) + lc;
+              float a_[V], b_[V], g_[V];
+              panel8(rl, lc, a_);
+              panel8(rl, lc + 32, b_);
+              if (row >= p.M) continue;
+#pragma unroll
+              for (int e = 0; e < V; ++e) a_[e] += bias[e], b_[e] += bias2[e];
+              if (aux) {
+                st8bf(aux + (size_t)row * p.ldaux + ca, a_, V);
+                st8bf(aux + (size_t)row * p.ldaux + cbb, b_, V);
+              }
+#pragma unroll
+              for (int e = 0; e < V; ++e) g_[e] = a_[e] * sigmoidf_(a_[e]) * b_[e];
+              st8bf(Cb + (size_t)row * p.ldc + cg, g_, V);
+            } else {
+              float v[V];
+              panel8(rl, lc, v);
+              if (row >= p.M || nv <= 0) continue;
+#pragma unroll
+              for (int e = 0; e < V; ++e) v[e] += bias[e];
+              if constexpr (EPI == MVIT_EPI_STORE) {
+                const size_t o = (size_t)row * p.ldc + col;
+                if (atomic) {
+                  for (int e = 0; e < nv; ++e) atomicAdd(Cf + o + e, v[e]);
+                } else if (out_f32) {
+                  st8f(Cf + o, v, nv);
+                } else {
+                  if (p.flags & MVIT_ACCUM_BF16) {
+                    float old[V];
+                    ld8bf(Cb + o, old, nv);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[e] += old[e];
+                  }
+                  st8bf(Cb + o, v, nv);
+                }
+              } else if constexpr (EPI == MVIT_EPI_GELU) {
+                if (p.aux) st8bf((bf16_t*)p.aux + (size_t)row * p.ldaux + col, v, nv);
+                float g_[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) g_[e] = gelu_erf(v[e]);
+                st8bf(Cb + (size_t)row * p.ldc + col, g_, nv);
+              } else if constexpr (EPI == MVIT_EPI_RESID) {
+                const size_t o = (size_t)row * p.ldc + col;
+                float r_[V];
+                ld8f(p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o, r_, nv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) r_[e] += gam[e] * v[e];
+                st8f(Cf + o, r_, nv);
+              } else if constexpr (EPI == MVIT_EPI_PATCH) {
+                const int img = row / p.patch_P, pp = row - img * p.patch_P;
+                const size_t o = (size_t)(img * p.patch_ntok + p.patch_prefix + pp) * p.ldc + col;
+                for (int e = 0; e < nv; ++e) Cf[o + e] = v[e] + p.pos[(size_t)pp * p.N + col + e];
+              } else if constexpr (EPI == MVIT_EPI_STATS) {
+                st8bf(Cb + (size_t)row * p.ldc + col, v, nv);
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                  if (e < nv) st_s[e] += v[e], st_q[e] += v[e] * v[e];
+              } else if constexpr (EPI == MVIT_EPI_DSWIGLU) {
+                // gate columns col..col+7 live at packed positions ca.. (a) and ca+32.. (b) of the saved pre-activation
+                const bf16_t* u = (const bf16_t*)p.aux;
+                const int ca = ((col >> 5) << 6) + (col & 31);
+                float a_[V], b_[V], da[V], db[V];
+                ld8bf(u + (size_t)row * p.ldaux + ca, a_, nv);
+                ld8bf(u + (size_t)row * p.ldaux + ca + 32, b_, nv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                  const float sg = sigmoidf_(a_[e]);
+                  da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
+                  db[e] = v[e] * a_[e] * sg;
+                }
+                st8bf(Cb + (size_t)row * p.ldc + ca, da, nv);
+                st8bf(Cb + (size_t)row * p.ldc + ca + 32, db, nv);
+              } else if constexpr (EPI == MVIT_EPI_DGELU) {
+                float u_[V], o_[V];
+                ld8bf((const bf16_t*)p.aux + (size_t)row * p.ldaux + col, u_, nv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) o_[e] = v[e] * gelu_erf_grad(u_[e]);
+                st8bf(Cb + (size_t)row * p.ldc + col, o_, nv);
+              }
+            }
+          }
+        }
     }
-    if (lane < CPR) {
+
+    if constexpr (EPI == MVIT_EPI_STATS) {
+      // lanes with equal lane % CPR own the same V columns; then across the WAVES_M waves through LDS
+      float* red = (float*)(smem + last * BUF_BYTES) + (size_t)NW * SLAB;  // [WAVES_M][BN][2], behind the panels
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        const int c = wave_n * WTN + lc + e;
-        red[(wave_m * BN + c) * 2 + 0] = st_s[e];
-        red[(wave_m * BN + c) * 2 + 1] = st_q[e];
-      }
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
-      double s_ = 0., q_ = 0.;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) {
-        s_ += red[(w * BN + tid) * 2 + 0];
-        q_ += red[(w * BN + tid) * 2 + 1];
+        for (int o = CPR; o < 64; o <<= 1) {
+          st_s[e] += __shfl_xor(st_s[e], o, 64);
+          st_q[e] += __shfl_xor(st_q[e], o, 64);
+        }
       }
-      double* st = p.stats + (size_t)(blockIdx.x % p.nslots) * 2 * p.N;
-      atomicAdd(st + n0 + tid, s_);
-      atomicAdd(st + p.N + n0 + tid, q_);
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int c = wave_n * WTN + lc + e;
+          red[(wave_m * BN + c) * 2 + 0] = st_s[e];
+          red[(wave_m * BN + c) * 2 + 1] = st_q[e];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && en0 + tid < p.N) {
+        double s_ = 0., q_ = 0.;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          s_ += red[(w * BN + tid) * 2 + 0];
+          q_ += red[(w * BN + tid) * 2 + 1];
+        }
+        double* st = p.stats + (size_t)((blockIdx.x + vt) % p.nslots) * 2 * p.N;
+        atomicAdd(st + en0 + tid, s_);
+        atomicAdd(st + p.N + en0 + tid, q_);
+      }
     }
+    if (!has_next) break;
+    vt = vt_next;
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-constexpr size_t gemm_lds_bytes() {
-  constexpr size_t stages = (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
-  constexpr size_t panels = (size_t)(WAVES_M * WAVES_N) * (BM / WAVES_M) * (BN / WAVES_N + 4) * 4 + (size_t)WAVES_M * BN * 2 * 4;
-  return stages > panels ? stages : panels;
-}
+int gemm_num_cus();
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 int launch_one(const mvit_gemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  dim3 grid(tiles, 1, a.ksplit > 1 ? a.ksplit : 1);
   const size_t lds = gemm_lds_bytes<BM, BN, WAVES_M, WAVES_N>();
+  // persistent grid: as many blocks as fit the chip at once (LDS-limited), each walking several tiles
+  int per_cu = (int)((160 * 1024) / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  int gx = gemm_num_cus() * per_cu;
+  if (gx > tiles) gx = tiles;
+  dim3 grid(gx, 1, a.ksplit > 1 ? a.ksplit : 1);
   auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
   if (lds > 64 * 1024) {
     static bool raised = false;  // per instantiation
