@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--encoder", default="hoptimus0")
+    ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,15 +118,21 @@ def main():
         mod.grad_sync = sync
     batches = [synthetic_batch(1234 + rank * 1000 + i, a.batch, a.img, nc, dev) for i in range(4)]
 
+    lat = []
+    if a.mode == "infer":
+        model.eval()
+        run_graph, x_static, _ = eng.capture_inference(a.batch) if a.graph else (None, None, None)
+
     def step(i):
         x, y = batches[i % len(batches)]
         if a.mode == "train":
             mod.training_step({"image": x, "target": y}, i)
+        elif a.graph:
+            x_static.copy_(x)      # device-to-device; the tile batch is already resident
+            run_graph()
         else:
             eng.forward(x, train=False, bn_train=False)
 
-    if a.mode == "infer":
-        model.eval()
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -159,6 +166,18 @@ def main():
                                f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} (BASELINE.json configs[1])",
                    "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}"},
     }
+    if a.mode == "infer":
+        # p50 latency of one batch, measured after the throughput window with a sync per batch
+        ts = []
+        for i in range(min(a.steps, 20)):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(i)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        res["p50_batch_latency_ms"] = round(ts[len(ts) // 2] * 1e3, 3)
+        res["config"]["hipgraph"] = bool(a.graph)
     if flops_tile:
         res["model_flops_frac"] = round(value / world * flops_tile / PEAK_BF16, 4)
     if rank == 0:

@@ -542,6 +542,23 @@ class HipEngine:
             self._saved = NS(w=w, pk=pk, x=x, convs=convs, bn_train=bn_train)
         return out if in_dtype == torch.float32 else out.to(in_dtype)
 
+    # ------------------------------------------------------------------ hipGraph-captured inference
+    def capture_inference(self, batch):
+        """Capture the eval-mode forward for a fixed batch size into a hipGraph (BASELINE config 5).
+
+        Returns (run, x_static, out_static): copy a batch into x_static, call run(), read out_static.  Every launch of
+        the forward goes through the C-ABI on the capture stream; nothing allocates or synchronises once the workspace,
+        weight packs and tap tables exist, so one warm-up call precedes the capture."""
+        dev = self._require_gpu()
+        c = self._config()
+        x_static = torch.zeros(batch, 3, c.S, c.S, device=dev, dtype=torch.float32)
+        self.forward(x_static, train=False, bn_train=False)      # warm-up: allocations, packs, LDS attributes
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out_static = self.forward(x_static, train=False, bn_train=False)
+        return graph.replay, x_static, out_static
+
     # ------------------------------------------------------------------ backward
     def _wgrad(self, w, i, src, r_in, cin_pad, ld, r_out, stride, dpre, cout):
         """dW^T[(ky,kx,c), co] += sum_pixels im2col(X)[m, (ky,kx,c)] * dY[m, co]: TN MFMA GEMM, window gathered on the

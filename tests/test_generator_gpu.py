@@ -110,3 +110,39 @@ def test_backward_matches_oracle_autograd(cfgname, img, nc, B):
     cos_ac = float((av * rv).sum() / (av.norm() * rv.norm()))
     assert cos > min(0.9995, cos_ac), (cos, cos_ac)
     assert abs(float(gv.norm() / rv.norm()) - 1) < 2e-2
+
+
+def test_graph_captured_inference_matches_eager():
+    """hipGraph replay of the eval forward (BASELINE config 5) gives the eager result, also for a second batch."""
+    from oracle import synth_batch
+    cfg, p, model = _load("tiny_swiglu", 128, 16, 5)
+    model.eval()
+    eng = model._engine
+    run, x_static, out_static = eng.capture_inference(3)
+    for seed in (1, 2):
+        x, _ = synth_batch(seed, 3, 128, 16)
+        x_static.copy_(x.cuda())
+        run()
+        torch.cuda.synchronize()
+        got = out_static.clone()
+        with torch.no_grad():
+            ref = model(x.cuda())
+        assert torch.equal(got, ref)
+
+
+def test_512_tiles_ragged_tokens():
+    """512x512 tiles (N = 36*36+5 = 1301 tokens, regrid 36->32): forward parity vs the oracle (BASELINE config 4 shape)."""
+    from oracle import VIT_CONFIGS, det_state_dict, generator_forward, synth_batch
+    from oracle.model import generator_state_shapes
+    from miphei_vit_amd.generators import get_vitmatte
+    cfg = VIT_CONFIGS["tiny_swiglu"]
+    sd = det_state_dict(generator_state_shapes(cfg, 512, 3), seed=4, layerscale=0.5)
+    p = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    model = get_vitmatte("tiny_swiglu", 512, 3, use_lora=True, pretrained=False)
+    model.load_state_dict(p)
+    model.cuda().eval()
+    x, _ = synth_batch(4, 1, 512, 3)
+    with torch.no_grad():
+        out = model(x.cuda()).cpu()
+        ref = generator_forward(p, x, cfg, 3, training=False)
+    assert float(_chan_rel_mse(out, ref).max()) < REL_MSE
