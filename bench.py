@@ -157,13 +157,14 @@ def main():
     value = tiles / dt
     flops_tile = (FLOPS_TRAIN if a.mode == "train" else FLOPS_FWD).get(a.img)
 
+    cfg_idx = 1 if a.mode == "train" else 4
     res = {
         "metric": "training tiles/sec (256x256 H&E->16ch mIF)" if a.mode == "train" else "inference tiles/sec",
         "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) {a.mode} step, "
-                               f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} (BASELINE.json configs[1])",
+                               f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} (BASELINE.json configs[{cfg_idx}])",
                    "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}"},
     }
     if a.mode == "infer":
