@@ -92,8 +92,12 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_ddp = os.environ.get("MIPHEI_FORCE_DDP", "0") == "1"  # run the RCCL exchange even on one rank (testing)
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from miphei_vit_amd import ops
@@ -112,8 +116,8 @@ def main():
     mod = ModelModule(model, None, 2e-4 * a.batch ** 0.5, 0., WeightedMSELoss(50.0, weights)).to(dev)
     mod.total_iters = 100000
     mod.nan_check_every = 10 ** 9   # the guard's host copy is exercised in tests, not inside the timed region
-    if world > 1:
-        sync = DataParallelSync(eng)
+    if world > 1 or force_ddp:
+        sync = DataParallelSync(eng, force=force_ddp)
         sync.broadcast_parameters(0)
         mod.grad_sync = sync
     batches = [synthetic_batch(1234 + rank * 1000 + i, a.batch, a.img, nc, dev) for i in range(4)]
@@ -186,14 +190,29 @@ def main():
             ach = probe["flops"] / (probe["ms"] * 1e-3)
             res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE>",
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16, 4), "traffic": None, "launches": probe["n"],
+                               "frac": round(ach / PEAK_BF16, 4), "traffic": pmc_traffic(), "launches": probe["n"],
                                "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
         if not a.no_cpu_baseline and world == 1 and a.mode == "train":
             res["cpu_baseline"], res["parity"] = cpu_baseline(model, a, nc, weights, dev)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE runs, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction; L2-side fabric
+    requests, i.e. Infinity-Cache hits are included).  None when the summary is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        for name, v in k.items():
+            if "gemm_kernel<256, 128, 4, 2, 0, 0>" in name:
+                return round(v["hbm_bytes_per_launch_corrected"])
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def cpu_baseline(model, a, nc, weights, dev):

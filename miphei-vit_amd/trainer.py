@@ -15,24 +15,25 @@ import torch.distributed as dist
 class DataParallelSync:
     """Averages the flat gradient buffer over ranks; ``decoder_ready`` is called from inside ``engine.backward``."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, force=False):
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path on one rank
         self._work = None
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.active:
             fl = self.engine._ensure_flat()
             dist.broadcast(fl.flat, src=src, group=self.group)
             self.engine._pack_key = None
 
     def decoder_ready(self):
-        if self.world > 1:
+        if self.active:
             dec, _ = self.engine.grad_buckets()
             self._work = dist.all_reduce(dec, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        if self.world > 1:
+        if self.active:
             dec, lora = self.engine.grad_buckets()
             w2 = dist.all_reduce(lora, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if lora.numel() else None
             if self._work is not None:
@@ -40,7 +41,8 @@ class DataParallelSync:
                 self._work = None
             if w2 is not None:
                 w2.wait()
-            self.engine._flat.gflat.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.engine._flat.gflat.mul_(1.0 / self.world)
 
 
 def allreduce_mean_(flat, world, group=None):
