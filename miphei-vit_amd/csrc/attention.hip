@@ -125,11 +125,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
 
+    if (q0 >= N) {  // wave-uniform: this wave's 32 query rows are all padding
+      __syncthreads();
+      continue;
+    }
+    const bool kt1_live = kv0 + 32 < N;  // second 32-key half of the tile holds at least one real key
     f32x16 st[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) st[kt][r] = kt == 1 && !kt1_live ? -1e30f : 0.f;
+      if (kt == 1 && !kt1_live) continue;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
       const int kt = s2 >> 1, h2 = s2 & 1;
+      if (kt == 1 && !kt1_live) continue;  // P is exactly 0 there
       float pv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) pv[e] = st[kt][8 * h2 + e];
@@ -287,11 +294,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
+    if (blockIdx.x * 128 + wave * 32 >= N) {  // dead wave (padding rows only)
+      __syncthreads();
+      continue;
+    }
+    const bool kt1_live = kv0 + 32 < N;
     f32x16 st[2], dp[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kt][r] = 0.f, dp[kt][r] = 0.f;
+      if (kt == 1 && !kt1_live) continue;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
       const int kt = s2 >> 1, h2 = s2 & 1;
+      if (kt == 1 && !kt1_live) continue;  // dS is exactly 0 there
       float pv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) pv[e] = st[kt][8 * h2 + e];
@@ -407,11 +421,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     const char* Ds = Qs + TILE_BYTES;
     const float* Ls = LD + cur * 128;
     const int qt0 = t * KVB;
+    if (blockIdx.x * 128 + wave * 32 >= N) {  // dead wave (padding keys only)
+      if (more) store_ld(cur ^ 1);
+      __syncthreads();
+      continue;
+    }
+    const bool qt1_live = qt0 + 32 < N;
     f32x16 st[2], dp[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[qt][r] = 0.f, dp[qt][r] = 0.f;
+      if (qt == 1 && !qt1_live) continue;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 a = *(const bf16x8*)(Qs + swz(32 * qt + l31, 2 * s + half));
@@ -436,6 +457,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
       const int qt = s2 >> 1, h2 = s2 & 1;
+      if (qt == 1 && !qt1_live) continue;  // P = dS = 0 for padding query rows
       float pv[8], dv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) pv[e] = st[qt][8 * h2 + e], dv[e] = dp[qt][8 * h2 + e];
