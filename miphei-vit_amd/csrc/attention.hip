@@ -69,6 +69,18 @@ __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rsrc, char* tile
   }
 }
 
+// 4-deep ring of [K|V] (or [Q|dO]) tile pairs: up to 3 tiles of DMA stay in flight, so after the first tile the
+// loop never waits on memory latency.  Counted vmcnt (4 DMA instructions per thread per tile pair) + raw s_barrier.
+constexpr int NRING = 4;
+__device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
+  if (ahead >= 2)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (ahead == 1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   union { uint32_t u[4]; bf16x8 v; } r;
 #pragma unroll
@@ -79,7 +91,7 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // ------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, AttnDims dm) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][K|V]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
@@ -111,24 +123,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
   const int ntiles = (N + KVB - 1) / KVB;
   const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
-  dma_rows(rK, smem, 0, N, Dh, (unsigned)rs, tid);
-  dma_rows(rV, smem + TILE_BYTES, 0, N, Dh, (unsigned)rs, tid);
-  __syncthreads();
+  auto issue = [&](int t) {
+    char* dst = smem + (t & (NRING - 1)) * 2 * TILE_BYTES;
+    dma_rows(rK, dst, t * KVB, N, Dh, (unsigned)rs, tid);
+    dma_rows(rV, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)rs, tid);
+  };
+  for (int t = 0; t < NRING - 1 && t < ntiles; ++t) issue(t);
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      dma_rows(rK, smem + (cur ^ 1) * 2 * TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
-      dma_rows(rV, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
-    }
+    const int cur = t & (NRING - 1);
+    wait_tiles_in_flight(min(NRING - 2, ntiles - 1 - t));
+    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (ring slot of t+3)
+    if (t + NRING - 1 < ntiles) issue(t + NRING - 1);
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
 
-    if (q0 >= N) {  // wave-uniform: this wave's 32 query rows are all padding
-      __syncthreads();
-      continue;
-    }
+    if (q0 >= N) continue;  // wave-uniform: this wave's 32 query rows are all padding
     const bool kt1_live = kv0 + 32 < N;  // second 32-key half of the tile holds at least one real key
     f32x16 st[2];
 #pragma unroll
@@ -193,7 +203,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[dt], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
                                                           bf16_t* __restrict__ dqkv, AttnDims dm) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
@@ -281,23 +290,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 
   const int ntiles = (N + KVB - 1) / KVB;
   const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
-  dma_rows(rK, smem, 0, N, Dh, (unsigned)rs, tid);
-  dma_rows(rV, smem + TILE_BYTES, 0, N, Dh, (unsigned)rs, tid);
-  __syncthreads();
+  auto issue = [&](int t) {
+    char* dst = smem + (t & (NRING - 1)) * 2 * TILE_BYTES;
+    dma_rows(rK, dst, t * KVB, N, Dh, (unsigned)rs, tid);
+    dma_rows(rV, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)rs, tid);
+  };
+  for (int t = 0; t < NRING - 1 && t < ntiles; ++t) issue(t);
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      dma_rows(rK, smem + (cur ^ 1) * 2 * TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
-      dma_rows(rV, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
-    }
+    const int cur = t & (NRING - 1);
+    wait_tiles_in_flight(min(NRING - 2, ntiles - 1 - t));
+    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (ring slot of t+3)
+    if (t + NRING - 1 < ntiles) issue(t + NRING - 1);
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
-    if (blockIdx.x * 128 + wave * 32 >= N) {  // dead wave (padding rows only)
-      __syncthreads();
-      continue;
-    }
+    if (blockIdx.x * 128 + wave * 32 >= N) continue;  // dead wave (padding rows only)
     const bool kt1_live = kv0 + 32 < N;
     f32x16 st[2], dp[2];
 #pragma unroll
@@ -335,7 +342,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb, dqacc[dt], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
   if (q < N) {
     bf16_t* orow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * Dh;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ Dv,
                                                            bf16_t* __restrict__ dqkv, AttnDims dm) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 2 * 2 * KVB * 4];  // [buf][Q|dO] + [buf][L|D]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][Q|dO] + L[Npad] + D[Npad] (f32)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
@@ -370,7 +376,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const bf16_t* vb = kb + (size_t)dm.H * Dh;
   const bf16_t* dob = dO + (size_t)b * N * ors + (size_t)h * Dh;
   const int key = blockIdx.x * 128 + wave * 32 + l31;
-  float* LD = (float*)(smem + 4 * TILE_BYTES);  // [buf][2][64]
+  const int Npad = ((N + KVB - 1) / KVB) * KVB;
+  float* LD = (float*)(smem + NRING * 2 * TILE_BYTES);  // L[Npad] (log2 units) then D[Npad]
 
   bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -391,41 +398,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) dkacc[i][r] = 0.f, dvacc[i][r] = 0.f;
 
-  float rl = 0.f;
   const __amdgpu_buffer_rsrc_t rQ = make_rsrc(qb), rD = make_rsrc(dob);
   const int ntiles = (N + KVB - 1) / KVB;
-  auto load_ld = [&](int row0) {
-    // threads 0..63: L, 64..127: D
-    if (tid < 128) {
-      const int i = tid & 63, qq = row0 + i;
-      rl = qq < N ? (tid < 64 ? lse[(size_t)bh * N + qq] * LOG2E : Dv[(size_t)bh * N + qq]) : 0.f;
-    }
+  auto issue = [&](int t) {
+    char* dst = smem + (t & (NRING - 1)) * 2 * TILE_BYTES;
+    dma_rows(rQ, dst, t * KVB, N, Dh, (unsigned)rs, tid);
+    dma_rows(rD, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)ors, tid);
   };
-  auto store_ld = [&](int buf) {
-    if (tid < 128) LD[buf * 128 + tid] = rl;
-  };
-  dma_rows(rQ, smem, 0, N, Dh, (unsigned)rs, tid);
-  dma_rows(rD, smem + TILE_BYTES, 0, N, Dh, (unsigned)ors, tid);
-  load_ld(0);
-  store_ld(0);
-  __syncthreads();
+  for (int t = 0; t < NRING - 1 && t < ntiles; ++t) issue(t);
+  for (int i = tid; i < Npad; i += 256) {  // per-row log-sum-exp and dO.O of the whole head (published by the first barrier)
+    LD[i] = i < N ? lse[(size_t)bh * N + i] * LOG2E : 0.f;
+    LD[Npad + i] = i < N ? Dv[(size_t)bh * N + i] : 0.f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      dma_rows(rQ, smem + (cur ^ 1) * 2 * TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)rs, tid);
-      dma_rows(rD, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, (t + 1) * KVB, N, Dh, (unsigned)ors, tid);
-      load_ld((t + 1) * KVB);
-    }
+    const int cur = t & (NRING - 1);
+    wait_tiles_in_flight(min(NRING - 2, ntiles - 1 - t));
+    __builtin_amdgcn_s_barrier();
+    if (t + NRING - 1 < ntiles) issue(t + NRING - 1);
     const char* Qs = smem + cur * 2 * TILE_BYTES;
     const char* Ds = Qs + TILE_BYTES;
-    const float* Ls = LD + cur * 128;
     const int qt0 = t * KVB;
-    if (blockIdx.x * 128 + wave * 32 >= N) {  // dead wave (padding keys only)
-      if (more) store_ld(cur ^ 1);
-      __syncthreads();
-      continue;
-    }
+    const float* Ls = LD + qt0;
+    if (blockIdx.x * 128 + wave * 32 >= N) continue;  // dead wave (padding keys only)
     const bool qt1_live = qt0 + 32 < N;
     f32x16 st[2], dp[2];
 #pragma unroll
@@ -443,7 +438,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int qb4 = 32 * qt + 8 * g + 4 * half;  // 4 consecutive query rows per register group
-        const float4 L4 = *(const float4*)(Ls + qb4), D4 = *(const float4*)(Ls + 64 + qb4);
+        const float4 L4 = *(const float4*)(Ls + qb4), D4 = *(const float4*)(Ls + Npad + qb4);
         const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv_[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -472,8 +467,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb, dkacc[dt], 0, 0, 0);
       }
     }
-    if (more) store_ld(cur ^ 1);
-    __syncthreads();
   }
   if (key < N) {
     bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)(dm.H + h) * Dh;
@@ -505,7 +498,7 @@ MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING * 2 * TILE_BYTES, (hipStream_t)stream,
                      (const bf16_t*)qkv, (bf16_t*)out, lse, dm);
   return MVIT_LAUNCH_CHECK();
 }
@@ -519,9 +512,17 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_
   const long long tot = (long long)B * N * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
                      (const bf16_t*)d_out, dsum, dm);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 127) / 128, B * H), dim3(256), 0, s, (const bf16_t*)qkv,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
                      (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 127) / 128, B * H), dim3(256), 0, s, (const bf16_t*)qkv,
+  const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;
+  static size_t lds_raised = 64 * 1024;  // grow-only: the attribute is a per-function maximum
+  if (lds_kv > lds_raised) {
+    if (lds_kv > 160 * 1024) return MVIT_EINVAL;
+    lds_raised = lds_kv;
+    if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess)
+      return MVIT_EINVAL;
+  }
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 127) / 128, B * H), dim3(256), lds_kv, s, (const bf16_t*)qkv,
                      (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   return MVIT_LAUNCH_CHECK();
 }
