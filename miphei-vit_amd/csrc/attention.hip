@@ -10,6 +10,7 @@
 // P (keys (e&3)+8*(e>>2)+4*half per 16-key step) is used directly as the MFMA k-slot order; the V^T
 // fragments are gathered in that same order, so P never moves between lanes.
 // Work split: 4 wavefronts x 32 queries per block, K/V tiles of 64 keys double-buffered in LDS.
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/miphei_hip.h"
 
@@ -72,6 +73,7 @@ __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rsrc, char* tile
 // 4-deep ring of [K|V] (or [Q|dO]) tile pairs: up to 3 tiles of DMA stay in flight, so after the first tile the
 // loop never waits on memory latency.  Counted vmcnt (4 DMA instructions per thread per tile pair) + raw s_barrier.
 constexpr int NRING = 4;
+constexpr float RESCALE_THR = 6.f;  // log2 units
 __device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
   if (ahead >= 2)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -139,7 +141,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int kv0 = t * KVB;
 
     if (q0 >= N) continue;  // wave-uniform: this wave's 32 query rows are all padding
-    const bool kt1_live = kv0 + 32 < N;  // second 32-key half of the tile holds at least one real key
+    auto tile_body = [&](auto ragged_tag) {
+      constexpr bool RAGGED = decltype(ragged_tag)::value;
+      const bool kt1_live = !RAGGED || kv0 + 32 < N;  // second 32-key half of the tile holds at least one real key
     f32x16 st[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
       }
     }
-    // online softmax (log2 domain): p = 2^(s*sc - m); the key mask is only needed in the ragged last tile
-    if (kv0 + KVB > N) {
+    // online softmax (log2 domain): p = 2^(s*sc - m); the key mask only exists in the ragged-tile instantiation
+    if constexpr (RAGGED) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -169,23 +173,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
     mloc = fmaxf(mloc * sc, -1e30f);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    // lazy rescale: O and l are only rescaled when the running max grows by more than 2^RESCALE_THR (rare after the
+    // first tiles); until then P is formed against the stale max and stays <= 2^RESCALE_THR
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    if (!__all(m_new - m_run <= RESCALE_THR)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -m_new));
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -m_run));
         st[kt][r] = p;
         lsum += p;
       }
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    l_run += lsum;
     // O^T += V^T P^T
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
@@ -203,6 +212,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[dt], 0, 0, 0);
       }
     }
+      };
+    if (kv0 + KVB > N)
+      tile_body(std::true_type{});
+    else
+      tile_body(std::false_type{});
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
@@ -305,7 +319,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
     if (blockIdx.x * 128 + wave * 32 >= N) continue;  // dead wave (padding rows only)
-    const bool kt1_live = kv0 + 32 < N;
+    auto tile_body = [&](auto ragged_tag) {
+      constexpr bool RAGGED = decltype(ragged_tag)::value;
+      const bool kt1_live = !RAGGED || kv0 + 32 < N;
     f32x16 st[2], dp[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float p = key < N ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -Lq)) : 0.f;
+        const float p = (!RAGGED || key < N) ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -Lq)) : 0.f;
         st[kt][r] = p * (dp[kt][r] - Dq) * dm.scale;  // dS^T
       }
     }
@@ -342,6 +358,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb, dqacc[dt], 0, 0, 0);
       }
     }
+      };
+    if (kv0 + KVB > N)
+      tile_body(std::true_type{});
+    else
+      tile_body(std::false_type{});
   }
   if (q < N) {
     bf16_t* orow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * Dh;
@@ -421,7 +442,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     const int qt0 = t * KVB;
     const float* Ls = LD + qt0;
     if (blockIdx.x * 128 + wave * 32 >= N) continue;  // dead wave (padding keys only)
-    const bool qt1_live = qt0 + 32 < N;
+    auto tile_body = [&](auto ragged_tag) {
+      constexpr bool RAGGED = decltype(ragged_tag)::value;
+      const bool qt1_live = !RAGGED || qt0 + 32 < N;
     f32x16 st[2], dp[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -443,7 +466,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float p = (qt0 + qb4 + e < N) ? __builtin_amdgcn_exp2f(fmaf(st[qt][r], sc, -Lv[e])) : 0.f;
+          const float p = (!RAGGED || qt0 + qb4 + e < N) ? __builtin_amdgcn_exp2f(fmaf(st[qt][r], sc, -Lv[e])) : 0.f;
           st[qt][r] = p;                                      // P
           dp[qt][r] = p * (dp[qt][r] - Dv_[e]) * dm.scale;   // dS
         }
@@ -467,6 +490,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb, dkacc[dt], 0, 0, 0);
       }
     }
+      };
+    if (qt0 + KVB > N)
+      tile_body(std::true_type{});
+    else
+      tile_body(std::false_type{});
   }
   if (key < N) {
     bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)(dm.H + h) * Dh;
