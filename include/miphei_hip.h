@@ -164,7 +164,8 @@ MVIT_API int mvit_heads_gate_fwd(const void* x, const float* W1, const float* b1
 MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, const float* b3, float* out /*NCHW f32*/,
                                  int B, int H, int W, int NH, mvit_stream_t stream);
 MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x, const void* G, const float* W3,
-                                 void* ET /*bf16 [NH*9, M]*/, float* dG /*[M,16]*/, float* dXc /*[M,32]*/, float* db3, int B,
+                                 void* ET /*bf16 [NH*9, M]*/, float* dG /*[M,16]*/, float* dXc /*[M,32]*/,
+                                 float* db3 /*[64 slots][32] partial sums, zeroed; sum over slots*/, int B,
                                  int H, int W, int NH, mvit_stream_t stream);
 MVIT_API int mvit_heads_gate_bwd(const void* x, const void* G, const float* dG, const float* dXc, const float* W1,
                                  const float* b1, const float* scale, const float* shift, const float* mean,

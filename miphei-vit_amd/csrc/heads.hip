@@ -18,6 +18,7 @@ constexpr int XC = 32;   // feature channels
 constexpr int HC = 16;   // hidden channels of the gate (F_int = 32 // 2)
 constexpr int MAXH = 16; // heads
 constexpr int NMOM = XC + XC * XC;
+constexpr int DB3_SLOTS = 64; // db3 partial sums: [DB3_SLOTS][32] floats (one 128-byte line per slot)
 
 __device__ __forceinline__ void load_x32(const bf16_t* __restrict__ p, float (&x)[XC]) {
 #pragma unroll
@@ -226,6 +227,9 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
   __syncthreads();
   const long long M = (long long)B * H * W;
   const size_t plane = (size_t)H * W;
+  float db_acc[MAXH];
+#pragma unroll
+  for (int h = 0; h < MAXH; ++h) db_acc[h] = 0.f;
   for (long long q0 = (long long)blockIdx.x * 256; q0 < M; q0 += (long long)gridDim.x * 256) {
     const long long q = q0 + threadIdx.x;
     const bool live = q < M;
@@ -277,14 +281,22 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
         dx[c] += gh * v[c];
       }
       if (live) dG[(size_t)q * MAXH + h] = dg;
-      const float s = wave_sum(dzc);
-      if ((threadIdx.x & 63) == 0) atomicAdd(db3 + h, s);
+#pragma unroll
+      for (int hh = 0; hh < MAXH; ++hh)
+        if (hh == h) db_acc[hh] += dzc;
     }
     if (live) {
 #pragma unroll
       for (int k = 0; k < XC / 4; ++k)
         ((float4*)(dXc + (size_t)q * XC))[k] = make_float4(dx[4 * k], dx[4 * k + 1], dx[4 * k + 2], dx[4 * k + 3]);
     }
+  }
+  // db3[h] += sum_p dz[p,h]: one atomic per wave and head, spread over DB3_SLOTS cache lines (summed by the caller)
+  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % DB3_SLOTS;
+#pragma unroll
+  for (int h = 0; h < MAXH; ++h) {
+    const float s = wave_sum(db_acc[h]);
+    if ((threadIdx.x & 63) == 0 && h < NH) atomicAdd(db3 + slot * 32 + h, s);
   }
 }
 
@@ -520,7 +532,7 @@ MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x,
                                  float* dG, float* dXc, float* db3, int B, int H, int W, int NH, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (B <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
-  hipLaunchKernelGGL(conv_bwd_kernel, dim3(nblk((long long)B * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dY, Y,
+  hipLaunchKernelGGL(conv_bwd_kernel, dim3(nblk((long long)B * H * W, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dY, Y,
                      (const bf16_t*)x, (const bf16_t*)G, W3, (bf16_t*)ET, dG, dXc, db3, B, H, W, NH);
   return MVIT_LAUNCH_CHECK();
 }
@@ -533,7 +545,7 @@ MVIT_API int mvit_heads_gate_bwd(const void* x, const void* G, const float* dG, 
   MVIT_CLEAR_ERROR();
   if (M <= 0 || NH <= 0 || NH > MAXH || nslots <= 0) return MVIT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gate_bwd_reduce_kernel, dim3(nblk(M, GR_ROWS * 16, 2048)), dim3(256), 0, s, (const bf16_t*)x,
+  hipLaunchKernelGGL(gate_bwd_reduce_kernel, dim3(nblk(M, GR_ROWS * 16, 512)), dim3(256), 0, s, (const bf16_t*)x,
                      (const bf16_t*)G, dG, W1, b1, scale, shift, mean, rstd, gamma, W2, red, M, NH, nslots);
   hipLaunchKernelGGL(gate_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, red, mom_sum, W1, b1, mean, rstd, gamma, dW1, dgamma,
                      dbeta, dW2, db2, coef, NH, nslots, count);

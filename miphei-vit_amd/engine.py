@@ -378,6 +378,7 @@ class HipEngine:
             w.dXc = e(B * S * S, HEAD_C, dt=torch.float32)
             w.dF3 = e(B * S * S, HEAD_C)
             w.coef = e(nch, 2, dt=torch.float32)
+            w.db3_slots = z(64, 32, dt=torch.float32)
             w.dpre_c = [e(B * s1 * s1, 48), e(B * s2 * s2, 96), e(B * s3 * s3, 192)]
             w.dpre_f = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64), e(B * S * S, 32)]
             w.dcat = [e(B * s3 * s3, CONV_CH[3] + D), e(B * s2 * s2, CONV_CH[2] + FUS_OUT[0]),
@@ -592,7 +593,9 @@ class HipEngine:
         fl.gflat.zero_()
         dY = dY.to(torch.float32).contiguous()
         # ---- heads
-        ops.heads_conv_bwd(dY, w.out, w.F3, w.G, pk.W3k, w.ET, w.dG, w.dXc, fl.db3, B, S, S, c.NH)
+        w.db3_slots.zero_()
+        ops.heads_conv_bwd(dY, w.out, w.F3, w.G, pk.W3k, w.ET, w.dG, w.dXc, w.db3_slots, B, S, S, c.NH)
+        fl.db3.add_(w.db3_slots.sum(0)[:c.NH])
         xT = w.dyT[:HEAD_C * Mp].view(HEAD_C, Mp)
         ops.transpose_bf16(w.F3, xT, Mp, HEAD_C, HEAD_C, Mp)
         ks = max(1, min(512, Mp // 512))
