@@ -352,11 +352,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       }
     }
 
+    // Epilogues that READ per-element operands (residual stream, saved SwiGLU pre-activation) fetch them one slab
+    // ahead: otherwise every row pass would expose a full HBM round trip behind its dependent store.
+    constexpr bool AUX_PF = (EPI == MVIT_EPI_RESID || EPI == MVIT_EPI_DSWIGLU);
+    const bool vec_ok = nv == V && !scalar_io;
+    uint4 pre[2][NPASS][2];
+    auto issue_aux = [&](int slab, int q) {
+      if constexpr (AUX_PF) {
+#pragma unroll
+        for (int it = 0; it < NPASS; ++it) {
+          const int rl = it * RPP + lr;
+          const int row = em0 + wave_m * WTM + (slab >> 1) * 32 + 16 * (slab & 1) + rl;
+          const bool ok = vec_ok && row < p.M && (RPP <= 16 || rl < 16);
+          pre[q][it][0] = pre[q][it][1] = make_uint4(0, 0, 0, 0);
+          if (ok) {
+            if constexpr (EPI == MVIT_EPI_RESID) {
+              const float* rp = p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + (size_t)row * p.ldc + col;
+              pre[q][it][0] = ((const uint4*)rp)[0];
+              pre[q][it][1] = ((const uint4*)rp)[1];
+            } else {
+              const bf16_t* u = (const bf16_t*)p.aux + (size_t)row * p.ldaux + (((col >> 5) << 6) + (col & 31));
+              pre[q][it][0] = *(const uint4*)u;
+              pre[q][it][1] = *(const uint4*)(u + 32);
+            }
+          }
+        }
+      }
+    };
+    auto un8bf = [&](const uint4& t, float (&o)[V]) {
+      const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+    };
+
     if (!(p.flags & 0x800)) {  // (0x800: debug, no epilogue)
+      issue_aux(0, 0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+          constexpr int NSLAB = TM * 2;
+          const int slab = i * 2 + g;
+          if (slab + 1 < NSLAB) issue_aux(slab + 1, (slab + 1) & 1);
           // park rows 32*i + 16*g .. +15 of the wave's sub-tile (accumulator registers 8g .. 8g+7)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
@@ -414,7 +451,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
               } else if constexpr (EPI == MVIT_EPI_RESID) {
                 const size_t o = (size_t)row * p.ldc + col;
                 float r_[V];
-                ld8f(p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o, r_, nv);
+                if (vec_ok) {
+                  const uint4 t0 = pre[slab & 1][it][0], t1 = pre[slab & 1][it][1];
+                  r_[0] = __uint_as_float(t0.x), r_[1] = __uint_as_float(t0.y), r_[2] = __uint_as_float(t0.z), r_[3] = __uint_as_float(t0.w);
+                  r_[4] = __uint_as_float(t1.x), r_[5] = __uint_as_float(t1.y), r_[6] = __uint_as_float(t1.z), r_[7] = __uint_as_float(t1.w);
+                } else {
+                  ld8f(p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o, r_, nv);
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) r_[e] += gam[e] * v[e];
                 st8f(Cf + o, r_, nv);
@@ -432,8 +475,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
                 const bf16_t* u = (const bf16_t*)p.aux;
                 const int ca = ((col >> 5) << 6) + (col & 31);
                 float a_[V], b_[V], da[V], db[V];
-                ld8bf(u + (size_t)row * p.ldaux + ca, a_, nv);
-                ld8bf(u + (size_t)row * p.ldaux + ca + 32, b_, nv);
+                if (vec_ok) {
+                  un8bf(pre[slab & 1][it][0], a_);
+                  un8bf(pre[slab & 1][it][1], b_);
+                } else {
+                  ld8bf(u + (size_t)row * p.ldaux + ca, a_, nv);
+                  ld8bf(u + (size_t)row * p.ldaux + ca + 32, b_, nv);
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                   const float sg = sigmoidf_(a_[e]);
