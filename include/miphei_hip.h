@@ -186,6 +186,15 @@ MVIT_API int mvit_adam_clip_step(float* p, const float* g, float* m, float* v, c
                                  float beta1, float beta2, float eps, float bias_c1, float bias_c2, float max_norm,
                                  mvit_stream_t stream);
 
+/* ---------------------------------------------------------------- on-device input / output stage */
+/* dst(f32 NCHW)[b,c,p] = src(u8 NHWC)[b,p,c] * scale[c] + shift[c].  With scale = 1/std, shift = -mean/std this is
+ * NormalizationLayer("he") of src/dataset.py:545-575 (H-Optimus-0 mean/std, dataset.py:599-601) after the HWC->CHW of
+ * ToTensor; with scale = 1.8/255, shift = -0.9 the target transform (dataset.py:573).  HW % 4 == 0. */
+MVIT_API int mvit_u8_nhwc_to_f32_nchw(const void* src_u8, float* dst, const float* scale, const float* shift, int B, int C,
+                                      long long HW, mvit_stream_t stream);
+/* dst(u8)[i] = trunc(clamp((src[i]+0.9)/1.8, 0, 1) * 255): SavePredictionsCallback, src/callbacks.py:345-346.  n % 4 == 0. */
+MVIT_API int mvit_f32_to_u8_export(const float* src, void* dst_u8, long long n, mvit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ SIGNATURES = {
     "mvit_heads_gate_bwd": [vp] * 21 + [ll, ci, ci, cd, vp],
     "mvit_wmse_fwd_bwd": [vp, vp, vp, vp, vp, ci, ci, ll, cf, vp],
     "mvit_sqnorm": [vp, vp, ll, vp],
+    "mvit_u8_nhwc_to_f32_nchw": [vp, vp, vp, vp, ci, ci, ll, vp],
+    "mvit_f32_to_u8_export": [vp, vp, ll, vp],
     "mvit_adam_clip_step": [vp, vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, cf, vp],
 }
 

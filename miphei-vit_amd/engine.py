@@ -269,6 +269,15 @@ class HipEngine:
             B2[:, 2 * D:, r:] = (c.alpha * Bv).transpose(1, 2)
             pk.B2 = B2                                                              # [L, 3D, 2r] bf16
             pk.AcatT = pk.Acat.transpose(1, 2).to(bf).contiguous()                 # [L, 2r, D]: B operand of t = h @ A
+            if not need_bwd:
+                # inference: fold the adapters into the packed projection, W' = W + alpha * (A B)^T on the q and v rows
+                # (SURVEY.md section 8f row 1 "LoRA merge"); the rank-2r K extension and the x @ A product disappear
+                pk.wqkv_merged = []
+                for l, blk in enumerate(vit.blocks):
+                    wm = f32(blk.attn.qkv.qkv.weight).clone()
+                    wm[:D] += c.alpha * (Aq[l] @ Bq[l]).t()
+                    wm[2 * D:] += c.alpha * (Av[l] @ Bv[l]).t()
+                    pk.wqkv_merged.append(wm.to(bf).contiguous())
             if need_bwd:
                 pk.Acat16 = pk.Acat.to(bf)                                          # B2 operand of the dh1 GEMM
                 pk.Bq16, pk.Bv16 = (c.alpha * Bq).to(bf).contiguous(), (c.alpha * Bv).to(bf).contiguous()  # [L, r, D]
@@ -424,7 +433,9 @@ class HipEngine:
             xmid = w.x_mid[i]
             xout = w.x_in[l + 1] if train else w.x_in[0]
             ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
-            if c.lora:
+            if c.lora and not train:
+                ops.gemm(w.h1[i], pk.wqkv_merged[l], w.qkv[i], bias=b.bqkv)
+            elif c.lora:
                 ops.skinny_xw(w.h1[i], pk.AcatT[l], w.t[i])
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv, a2=w.t[i], b2=pk.B2[l], K2=2 * c.rank)
             else:

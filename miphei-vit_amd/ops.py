@@ -246,3 +246,16 @@ def sqnorm(x, out):
 
 def adam_clip_step(p, g, m, v, sqn, lr, beta1, beta2, eps, bc1, bc2, max_norm):
     _call("mvit_adam_clip_step", _p(p), _p(g), _p(m), _p(v), _p(sqn), p.numel(), lr, beta1, beta2, eps, bc1, bc2, max_norm)
+
+
+def u8_nhwc_to_f32_nchw(src, dst, scale, shift):
+    B, H, W, Cc = src.shape
+    assert src.dtype == torch.uint8 and dst.dtype == torch.float32
+    _call("mvit_u8_nhwc_to_f32_nchw", _p(src), _p(dst), _p(scale), _p(shift), B, Cc, H * W)
+    return dst
+
+
+def f32_to_u8_export(src, dst):
+    assert src.dtype == torch.float32 and dst.dtype == torch.uint8
+    _call("mvit_f32_to_u8_export", _p(src), _p(dst), src.numel())
+    return dst

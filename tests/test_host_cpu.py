@@ -133,3 +133,46 @@ def test_gloo_world2_gradient_exchange(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_checkpoint_prune_load_validate(tmp_path):
+    from miphei_vit_amd.checkpoint import (get_generator_state_dict, load_generator_checkpoint, save_pruned_safetensors,
+                                           validate_load_info)
+    from miphei_vit_amd.generators import get_vitmatte
+    torch.manual_seed(0)
+    src = get_vitmatte("tiny_swiglu", 128, 3, use_lora=True, pretrained=False)
+    with torch.no_grad():
+        for p in src.parameters():
+            if p.requires_grad:
+                p.add_(torch.randn_like(p) * 0.1)
+    keys = save_pruned_safetensors(src, tmp_path / "model.safetensors")
+    assert all((".lora" in k) or k.startswith("decoder.") for k in keys)
+    assert not any(k.startswith("encoder.vit.") and ".lora" not in k for k in keys)
+    dst = get_vitmatte("tiny_swiglu", 128, 3, use_lora=True, pretrained=False)
+    info = load_generator_checkpoint(dst, tmp_path)
+    assert info.missing_keys and all(k.startswith("encoder.vit.") for k in info.missing_keys)
+    a, b = src.state_dict(), dst.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in keys)
+    # error conventions of validate_load_info
+    from safetensors.torch import load_file, save_file
+    sd = load_file(str(tmp_path / "model.safetensors"))
+    bad = dict(sd); bad["decoder.bogus"] = torch.zeros(1)
+    with pytest.raises(ValueError, match="Unexpected"):
+        validate_load_info(dst.load_state_dict(bad, strict=False))
+    no_lora = {k: v for k, v in sd.items() if ".lora_q.A" not in k}
+    with pytest.raises(ValueError, match="Missing LoRA"):
+        validate_load_info(dst.load_state_dict(no_lora, strict=False))
+    no_dec = {k: v for k, v in sd.items() if k != "decoder.fusion_blks.0.conv.conv.weight"}
+    with pytest.raises(ValueError, match="Missing key"):
+        validate_load_info(dst.load_state_dict(no_dec, strict=False))
+    lightning = {"generator." + k: v for k, v in src.state_dict().items()}
+    lightning["loss_reconstruct.marker_weights"] = torch.ones(3)
+    assert sorted(get_generator_state_dict(lightning)) == sorted(src.state_dict())
+
+
+def test_pos_embed_resize_on_load():
+    from miphei_vit_amd.generators.foundation_models import VisionTransformer, resize_pos_embed_statedict
+    m = VisionTransformer(img_size=256, patch_size=14, embed_dim=96, depth=1, num_heads=3, mlp="swiglu", hidden=512)
+    sd = {"pos_embed": torch.randn(1, 16 * 16, 96)}   # checkpoint trained at 224 (16x16 grid)
+    out = resize_pos_embed_statedict(sd, m, 256)
+    assert out["pos_embed"].shape == (1, 18 * 18, 96)
