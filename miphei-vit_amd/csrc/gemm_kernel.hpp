@@ -100,6 +100,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   int m0 = 0, n0 = 0;
   __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2;
   ConvRow crow[A_CH];
+  unsigned baseA = 0, baseB = 0;  // dense operands: this lane's byte offset of chunk row 0 in K tile 0
+  int validA = 0, validB = 0;     // bit j: chunk row j lies inside M / N
 
   auto setup_tile = [&](int vt) {
     // virtual tile id -> XCD-aware, grouped tile coordinates (bijective for any tile count):
@@ -120,6 +122,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     rsB = make_rsrc(Bp + (size_t)n0 * p.ldb);
     rsA2 = make_rsrc(A2p ? A2p + (size_t)m0 * p.lda2 : Ap);
     rsB2 = make_rsrc(B2p ? B2p + (size_t)n0 * p.ldb2 : Bp);
+    baseA = ((unsigned)row_base * (unsigned)p.lda + (unsigned)c8s * 8u) * 2u;
+    baseB = ((unsigned)row_base * (unsigned)p.ldb + (unsigned)c8s * 8u) * 2u;
+    validA = validB = 0;
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) validA |= (m0 + row_base + RPI * j < p.M) ? (1 << j) : 0;
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) validB |= (n0 + row_base + RPI * j < p.N) ? (1 << j) : 0;
     if (AMODE != MVIT_A_DENSE) {
 #pragma unroll
       for (int j = 0; j < A_CH; ++j) {
@@ -195,8 +204,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       }
     }
   };
+  // full K tiles of dense main operands: the K advance rides on the scalar offset operand of the DMA and the per-lane
+  // offsets are per-tile constants -> a K step costs LPT x (s_mov m0 + buffer_load), no address VALU at all.
+  // (generic lambda on purpose: the DMA builtin only exists for the device target, and the host pass of hipcc must
+  // not instantiate the body or it silently drops the kernel's host stub)
+  auto issue_tile_fast = [&](int t, int buf, auto) {
+    char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
+    char* b = a + A_BYTES;
+    const int soff = t * (BK * 2);
+    const unsigned sa = (unsigned)(RPI * 2) * (unsigned)p.lda, sb = (unsigned)(RPI * 2) * (unsigned)p.ldb;
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      unsigned off = (validA >> j) & 1 ? baseA + (unsigned)j * sa : OOB;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, soff, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      unsigned off = (validB >> j) & 1 ? baseB + (unsigned)j * sb : OOB;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * RPI * 128), 16, off, soff, 0, 0);
+    }
+  };
   auto issue_tile = [&](int t, int buf) {
-    if (t < nk1)
+    if (AMODE == MVIT_A_DENSE && (t + 1) * BK <= p.K)
+      issue_tile_fast(t, buf, 0);
+    else if (t < nk1)
       issue_tile_impl(t, buf, std::false_type{});
     else
       issue_tile_impl(t, buf, std::true_type{});
