@@ -161,9 +161,9 @@ def main():
     value = tiles / dt
     flops_tile = (FLOPS_TRAIN if a.mode == "train" else FLOPS_FWD).get(a.img)
 
-    cfg_idx = 1 if a.mode == "train" else 4
+    cfg_idx = (1 if a.img == 256 else 3) if a.mode == "train" else 4
     res = {
-        "metric": "training tiles/sec (256x256 H&E->16ch mIF)" if a.mode == "train" else "inference tiles/sec",
+        "metric": f"training tiles/sec ({a.img}x{a.img} H&E->16ch mIF)" if a.mode == "train" else "inference tiles/sec",
         "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
