@@ -72,7 +72,8 @@ __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rsrc, char* tile
 
 // 4-deep ring of [K|V] (or [Q|dO]) tile pairs: up to 3 tiles of DMA stay in flight, so after the first tile the
 // loop never waits on memory latency.  Counted vmcnt (4 DMA instructions per thread per tile pair) + raw s_barrier.
-constexpr int NRING = 4;
+constexpr int NRING = 2;      // dkv kernel
+constexpr int NRING_Q = 2;    // query-stationary kernels (fwd, dq): smaller LDS footprint -> more blocks per CU
 constexpr float RESCALE_THR = 6.f;  // log2 units
 __device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
   if (ahead >= 2)
@@ -91,9 +92,9 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 }
 
 // ------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, AttnDims dm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][K|V]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
@@ -126,16 +127,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int ntiles = (N + KVB - 1) / KVB;
   const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
   auto issue = [&](int t) {
-    char* dst = smem + (t & (NRING - 1)) * 2 * TILE_BYTES;
+    char* dst = smem + (t & (NRING_Q - 1)) * 2 * TILE_BYTES;
     dma_rows(rK, dst, t * KVB, N, Dh, (unsigned)rs, tid);
     dma_rows(rV, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)rs, tid);
   };
-  for (int t = 0; t < NRING - 1 && t < ntiles; ++t) issue(t);
+  for (int t = 0; t < NRING_Q - 1 && t < ntiles; ++t) issue(t);
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & (NRING - 1);
-    wait_tiles_in_flight(min(NRING - 2, ntiles - 1 - t));
+    const int cur = t & (NRING_Q - 1);
+    wait_tiles_in_flight(min(NRING_Q - 2, ntiles - 1 - t));
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (ring slot of t+3)
-    if (t + NRING - 1 < ntiles) issue(t + NRING - 1);
+    if (t + NRING_Q - 1 < ntiles) issue(t + NRING_Q - 1);
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
@@ -265,10 +266,10 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 
 // ------------------------------------------------------------------ backward, dQ (query-stationary, S^T form)
 //   S^T = K Q^T, P = exp(S*scale - L), dP^T = V dO^T, dS^T = P*(dP^T - D)*scale, dQ^T += K^T dS^T
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
                                                           bf16_t* __restrict__ dqkv, AttnDims dm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][K|V]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
@@ -305,16 +306,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int ntiles = (N + KVB - 1) / KVB;
   const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
   auto issue = [&](int t) {
-    char* dst = smem + (t & (NRING - 1)) * 2 * TILE_BYTES;
+    char* dst = smem + (t & (NRING_Q - 1)) * 2 * TILE_BYTES;
     dma_rows(rK, dst, t * KVB, N, Dh, (unsigned)rs, tid);
     dma_rows(rV, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)rs, tid);
   };
-  for (int t = 0; t < NRING - 1 && t < ntiles; ++t) issue(t);
+  for (int t = 0; t < NRING_Q - 1 && t < ntiles; ++t) issue(t);
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & (NRING - 1);
-    wait_tiles_in_flight(min(NRING - 2, ntiles - 1 - t));
+    const int cur = t & (NRING_Q - 1);
+    wait_tiles_in_flight(min(NRING_Q - 2, ntiles - 1 - t));
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (ring slot of t+3)
-    if (t + NRING - 1 < ntiles) issue(t + NRING - 1);
+    if (t + NRING_Q - 1 < ntiles) issue(t + NRING_Q - 1);
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
@@ -322,42 +323,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     auto tile_body = [&](auto ragged_tag) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
       const bool kt1_live = !RAGGED || kv0 + 32 < N;
-    f32x16 st[2], dp[2];
+      // one 32-key sub-tile at a time: S^T, dP^T -> dS^T -> dQ^T
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < 2; ++kt) {
+        if (kt == 1 && !kt1_live) continue;  // dS is exactly 0 there
+        f32x16 st, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f, dp[kt][r] = 0.f;
-      if (kt == 1 && !kt1_live) continue;
+        for (int r = 0; r < 16; ++r) st[r] = 0.f, dp[r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
-        const bf16x8 v = *(const bf16x8*)(Vs + swz(32 * kt + l31, 2 * s + half));
-        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, dof[s], dp[kt], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st, 0, 0, 0);
+          const bf16x8 v = *(const bf16x8*)(Vs + swz(32 * kt + l31, 2 * s + half));
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, dof[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float p = (!RAGGED || key < N) ? __builtin_amdgcn_exp2f(fmaf(st[r], sc, -Lq)) : 0.f;
+          st[r] = p * (dp[r] - Dq) * dm.scale;  // dS^T
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float pv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = st[8 * h2 + e];
+          const bf16x8 dsb = pack8(pv);
+          const int kbase = 32 * kt + 16 * h2 + 4 * half;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
+            const bf16x8 a = join(tr_read4(Ks, kbase, cb, lane), tr_read4(Ks, kbase + 8, cb, lane));
+            dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb, dqacc[dt], 0, 0, 0);
+          }
+        }
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float p = (!RAGGED || key < N) ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -Lq)) : 0.f;
-        st[kt][r] = p * (dp[kt][r] - Dq) * dm.scale;  // dS^T
-      }
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const int kt = s2 >> 1, h2 = s2 & 1;
-      if (kt == 1 && !kt1_live) continue;  // dS is exactly 0 there
-      float pv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pv[e] = st[kt][8 * h2 + e];
-      const bf16x8 dsb = pack8(pv);
-      const int kbase = 32 * kt + 16 * h2 + 4 * half;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
-        const bf16x8 a = join(tr_read4(Ks, kbase, cb, lane), tr_read4(Ks, kbase + 8, cb, lane));
-        dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb, dqacc[dt], 0, 0, 0);
-      }
-    }
       };
     if (kv0 + KVB > N)
       tile_body(std::true_type{});
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 
 // ------------------------------------------------------------------ backward, dK / dV (key-stationary, S form)
 //   S = Q K^T, P = exp(S*scale - L_q), dP = dO V^T, dS = P*(dP - D_q)*scale, dV^T += dO^T P, dK^T += Q^T dS
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ Dv,
                                                            bf16_t* __restrict__ dqkv, AttnDims dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][Q|dO] + L[Npad] + D[Npad] (f32)
@@ -445,51 +445,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     auto tile_body = [&](auto ragged_tag) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
       const bool qt1_live = !RAGGED || qt0 + 32 < N;
-    f32x16 st[2], dp[2];
+      // one 32-row query sub-tile at a time: S, dP -> P, dS -> dV^T, dK^T (keeps the live accumulator set small)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < 2; ++qt) {
+        if (qt == 1 && !qt1_live) continue;  // P = dS = 0 for padding query rows
+        f32x16 st, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[qt][r] = 0.f, dp[qt][r] = 0.f;
-      if (qt == 1 && !qt1_live) continue;
+        for (int r = 0; r < 16; ++r) st[r] = 0.f, dp[r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 a = *(const bf16x8*)(Qs + swz(32 * qt + l31, 2 * s + half));
-        st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], st[qt], 0, 0, 0);
-        const bf16x8 g = *(const bf16x8*)(Ds + swz(32 * qt + l31, 2 * s + half));
-        dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, vf[s], dp[qt], 0, 0, 0);
-      }
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 a = *(const bf16x8*)(Qs + swz(32 * qt + l31, 2 * s + half));
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], st, 0, 0, 0);
+          const bf16x8 g = *(const bf16x8*)(Ds + swz(32 * qt + l31, 2 * s + half));
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, vf[s], dp, 0, 0, 0);
+        }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int qb4 = 32 * qt + 8 * g + 4 * half;  // 4 consecutive query rows per register group
-        const float4 L4 = *(const float4*)(Ls + qb4), D4 = *(const float4*)(Ls + Npad + qb4);
-        const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv_[4] = {D4.x, D4.y, D4.z, D4.w};
+        for (int g = 0; g < 4; ++g) {
+          const int qb4 = 32 * qt + 8 * g + 4 * half;  // 4 consecutive query rows per register group
+          const float4 L4 = *(const float4*)(Ls + qb4), D4 = *(const float4*)(Ls + Npad + qb4);
+          const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv_[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const float p = (!RAGGED || qt0 + qb4 + e < N) ? __builtin_amdgcn_exp2f(fmaf(st[qt][r], sc, -Lv[e])) : 0.f;
-          st[qt][r] = p;                                      // P
-          dp[qt][r] = p * (dp[qt][r] - Dv_[e]) * dm.scale;   // dS
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float p = (!RAGGED || qt0 + qb4 + e < N) ? __builtin_amdgcn_exp2f(fmaf(st[r], sc, -Lv[e])) : 0.f;
+            st[r] = p;                                  // P
+            dp[r] = p * (dp[r] - Dv_[e]) * dm.scale;   // dS
+          }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float pv[8], dv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = st[8 * h2 + e], dv[e] = dp[8 * h2 + e];
+          const bf16x8 pb = pack8(pv), dsb = pack8(dv);
+          const int qbase = 32 * qt + 16 * h2 + 4 * half;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
+            const bf16x8 a = join(tr_read4(Ds, qbase, cb, lane), tr_read4(Ds, qbase + 8, cb, lane));
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, dvacc[dt], 0, 0, 0);
+            const bf16x8 a2 = join(tr_read4(Qs, qbase, cb, lane), tr_read4(Qs, qbase + 8, cb, lane));
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb, dkacc[dt], 0, 0, 0);
+          }
         }
       }
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const int qt = s2 >> 1, h2 = s2 & 1;
-      if (qt == 1 && !qt1_live) continue;  // P = dS = 0 for padding query rows
-      float pv[8], dv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pv[e] = st[qt][8 * h2 + e], dv[e] = dp[qt][8 * h2 + e];
-      const bf16x8 pb = pack8(pv), dsb = pack8(dv);
-      const int qbase = 32 * qt + 16 * h2 + 4 * half;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
-        const bf16x8 a = join(tr_read4(Ds, qbase, cb, lane), tr_read4(Ds, qbase + 8, cb, lane));
-        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, dvacc[dt], 0, 0, 0);
-        const bf16x8 a2 = join(tr_read4(Qs, qbase, cb, lane), tr_read4(Qs, qbase + 8, cb, lane));
-        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb, dkacc[dt], 0, 0, 0);
-      }
-    }
       };
     if (qt0 + KVB > N)
       tile_body(std::true_type{});
@@ -526,7 +525,7 @@ MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING * 2 * TILE_BYTES, (hipStream_t)stream,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, (hipStream_t)stream,
                      (const bf16_t*)qkv, (bf16_t*)out, lse, dm);
   return MVIT_LAUNCH_CHECK();
 }
@@ -540,7 +539,7 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_
   const long long tot = (long long)B * N * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
                      (const bf16_t*)d_out, dsum, dm);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
                      (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;
   static size_t lds_raised = 64 * 1024;  // grow-only: the attribute is a per-function maximum
