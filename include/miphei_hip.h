@@ -195,6 +195,14 @@ MVIT_API int mvit_u8_nhwc_to_f32_nchw(const void* src_u8, float* dst, const floa
 /* dst(u8)[i] = trunc(clamp((src[i]+0.9)/1.8, 0, 1) * 255): SavePredictionsCallback, src/callbacks.py:345-346.  n % 4 == 0. */
 MVIT_API int mvit_f32_to_u8_export(const float* src, void* dst_u8, long long n, mvit_stream_t stream);
 
+/* ---------------------------------------------------------------- validation-time cell extractor */
+/* For every pixel with 0 < nuclei[b,p] <= max_label: counts[b,lab] += 1, sums_pred[b,lab,c] += pred[b,c,p] (and the same
+ * for target when given).  Tables are [B, max_label+1, C] / [B, max_label+1] f32, zeroed by the caller.
+ * MeanCellExtrator.extract_mean, src/utils.py:49-121 (torch.unique + scatter_add_ per image). */
+MVIT_API int mvit_cell_sums(const float* pred, const float* target, const int* nuclei, float* sums_pred,
+                            float* sums_target, float* counts, int B, int C, long long HW, int max_label,
+                            mvit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

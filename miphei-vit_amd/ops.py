@@ -259,3 +259,9 @@ def f32_to_u8_export(src, dst):
     assert src.dtype == torch.float32 and dst.dtype == torch.uint8
     _call("mvit_f32_to_u8_export", _p(src), _p(dst), src.numel())
     return dst
+
+
+def cell_sums(pred, target, nuclei, sums_p, sums_t, counts, max_label):
+    B, Cc, H, W = pred.shape
+    assert nuclei.dtype == torch.int32
+    _call("mvit_cell_sums", _p(pred), _p(target), _p(nuclei), _p(sums_p), _p(sums_t), _p(counts), B, Cc, H * W, max_label)
