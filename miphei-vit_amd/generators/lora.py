@@ -13,30 +13,27 @@ import torch.nn as nn
 
 
 class LoRALayer(nn.Module):
+    """Holds one adapter pair: A [in_dim, rank] ~ N(0, 1/rank), B [rank, out_dim] = 0 (so the adapter starts as a no-op)."""
+
     def __init__(self, in_dim, out_dim, rank, alpha):
         super().__init__()
-        std_dev = 1 / torch.sqrt(torch.tensor(rank).float())
-        self.A = nn.Parameter(torch.randn(in_dim, rank) * std_dev)
-        self.B = nn.Parameter(torch.zeros(rank, out_dim))
-        self.alpha = alpha
-        self.rank = rank
+        self.rank, self.alpha = int(rank), alpha
+        self.A = nn.Parameter(torch.randn(in_dim, self.rank) * float(self.rank) ** -0.5)
+        self.B = nn.Parameter(torch.zeros(self.rank, out_dim))
 
 
 class QkvWithLoRA(nn.Module):
+    """Wraps the packed qkv ``nn.Linear`` (kept as ``.qkv`` -> state-dict prefix ``attn.qkv.qkv``) with Q and V adapters."""
+
     def __init__(self, qkv, rank, alpha):
         super().__init__()
-        self.qkv = qkv
         self.dim = qkv.in_features
-        self.lora_q = LoRALayer(self.dim, self.dim, rank, alpha)
-        self.lora_v = LoRALayer(self.dim, self.dim, rank, alpha)
+        self.qkv = qkv
+        for name in ("lora_q", "lora_v"):
+            setattr(self, name, LoRALayer(self.dim, self.dim, rank, alpha))
 
-    @property
-    def in_features(self):
-        return self.qkv.in_features
-
-    @property
-    def out_features(self):
-        return self.qkv.out_features
+    in_features = property(lambda self: self.qkv.in_features)
+    out_features = property(lambda self: self.qkv.out_features)
 
 
 def apply_lora(model, rank, alpha):
