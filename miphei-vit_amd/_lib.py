@@ -84,6 +84,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The MI355X path has no fallback.")
+        # torch must load ITS HIP runtime first: libmiphei_hip.so then binds to that same libamdhip64 instance (same
+        # soname).  Loaded the other way round the process ends up with two runtimes and every launch on a torch stream
+        # fails with hipErrorNoDevice.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
