@@ -45,6 +45,11 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   const bool dense = a.amode == MVIT_A_DENSE;
   static const int big_tile = [] { const char* e = getenv("MVIT_GEMM_BIG_TILE"); return e ? atoi(e) : 1; }();
   const bool big = big_tile && a.M >= 1024;  // 8-wave 256x128 tile, 3-stage DMA pipeline
+  // 8-wave 256x256 tile (2 stages): 1.5x the arithmetic intensity per DMA'd byte; only when it still fills the chip
+  static const int huge_min_tiles = [] { const char* e = getenv("MVIT_GEMM_HUGE_MIN_TILES"); return e ? atoi(e) : 600; }();
+  const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const bool huge = big && dense && (a.N % 256 == 0) && tiles256 >= huge_min_tiles && a.ksplit <= 1;
+  if (huge) return launch_dense<256, 256, 2, 4>(a, s);
   if (a.epi == MVIT_EPI_SWIGLU) {
     if ((a.N % 128) || !dense) return MVIT_EINVAL;
     return big ? launch_dense<256, 128, 4, 2>(a, s) : launch_dense<128, 128, 2, 2>(a, s);
