@@ -1,0 +1,78 @@
+"""Training entry point with the reference's command-line shape:
+
+    python run.py +default_configs=miphei-vit ++train.max_steps=50
+    python -m torch.distributed.run --nproc-per-node 8 run.py +default_configs=miphei-vit ++train.devices=8
+
+Mirrors ``/root/reference/run.py`` + ``src/train.py:34-210`` for the parts on the MI355X hot path: compose the config,
+build generator / loss / ``ModelModule``, run the (fused) training steps, save ``model.safetensors`` (LoRA + decoder) with
+the reference key names.  Data loading is outside the path: tiles are synthetic and generated on the device.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main(argv):
+    from bench import synthetic_batch, synthetic_init_
+    from miphei_vit_amd.checkpoint import save_pruned_safetensors
+    from miphei_vit_amd.config import compose
+    from miphei_vit_amd.generators import get_generator
+    from miphei_vit_amd.loss import WeightedMSELoss, marker_weights_from_stats
+    from miphei_vit_amd.models import ModelModule
+    from miphei_vit_amd.trainer import DataParallelSync
+
+    cfg = compose(os.path.join(ROOT, "configs"), argv)
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    nc = len(cfg.data.targ_channel_names)
+    S, B = int(cfg.data.tile_size), int(cfg.train.batch_size)
+    with torch.device(dev):
+        generator = get_generator(cfg.model.model_name, S, 3, nc, cfg)
+    if not cfg.model.encoder.get("pretrained", True) and cfg.model.encoder.encoder_weights is None:
+        synthetic_init_(generator, seed=0)
+    if cfg.data.channel_stats_path:
+        stats = json.load(open(cfg.data.channel_stats_path))
+        weights = marker_weights_from_stats([stats[n]["std"] for n in cfg.data.targ_channel_names])
+    else:
+        from oracle.model import ORION_MARKER_WEIGHTS  # constants only (train.py:137-140 on the ORION channel_stats.json)
+        weights = torch.tensor(ORION_MARKER_WEIGHTS[:nc])
+    loss = WeightedMSELoss(cfg.train.losses.lambda_factor, weights)
+    module = ModelModule(generator, None, cfg.train.learning_rate_g * B ** 0.5, cfg.train.learning_rate_d, loss,
+                         gan_train=cfg.train.gan_train).to(dev)
+    steps = int(cfg.train.max_steps)
+    module.total_iters = steps
+    if world > 1:
+        sync = DataParallelSync(generator._engine)
+        sync.broadcast_parameters(0)
+        module.grad_sync = sync
+    t0 = time.perf_counter()
+    for i in range(steps):
+        x, y = synthetic_batch(1234 + rank * 1000 + i, B, S, nc, dev)
+        out = module.training_step({"image": x, "target": y}, i)
+        if rank == 0 and (i % 10 == 0 or i == steps - 1):
+            print(f"step {i:5d}  loss {float(out):.4f}  lr {module.current_lr(i):.3e}", flush=True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        dt = time.perf_counter() - t0
+        print(f"{steps} steps, {world * B * steps / dt:.1f} tiles/s")
+        logdir = os.path.join(ROOT, "logs")
+        os.makedirs(logdir, exist_ok=True)
+        save_pruned_safetensors(generator, os.path.join(logdir, "model.safetensors"))
+        print("saved", os.path.join(logdir, "model.safetensors"))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -176,3 +176,51 @@ def test_pos_embed_resize_on_load():
     sd = {"pos_embed": torch.randn(1, 16 * 16, 96)}   # checkpoint trained at 224 (16x16 grid)
     out = resize_pos_embed_statedict(sd, m, 256)
     assert out["pos_embed"].shape == (1, 18 * 18, 96)
+
+
+def test_config_compose_overlays_and_overrides():
+    from miphei_vit_amd.config import compose
+    cfg = compose(os.path.join(ROOT, "configs"), ["+default_configs=miphei-vit", "++train.epochs=100", "train.batch_size=8",
+                                                  "++model.encoder.encoder_weights=null"])
+    assert cfg.model.model_name == "myvitmatte" and cfg.model.encoder.encoder_name == "hoptimus0"
+    assert cfg.train.epochs == 100 and cfg.train.batch_size == 8 and cfg.train.gan_train is False
+    assert cfg.train.losses.lambda_factor == 50 and len(cfg.data.targ_channel_names) == 16
+    assert cfg.model.encoder.encoder_weights is None and cfg.get_path("model.encoder.pretrained") is False
+    tiny = compose(os.path.join(ROOT, "configs"), ["+default_configs=tiny"])
+    assert tiny.model.encoder.encoder_name == "tiny" and len(tiny.data.targ_channel_names) == 3
+
+
+_DDP_WORKER = r'''
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from miphei_vit_amd.trainer import DataParallelSync
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+n, n_lora = 1000, 300
+class FakeEngine:                      # the exchange only touches the flat buffers and the two bucket slices
+    def __init__(self):
+        g = torch.Generator().manual_seed(100 + rank)
+        self._flat = types.SimpleNamespace(flat=torch.full((n,), float(rank)), gflat=torch.randn(n, generator=g), n_lora=n_lora)
+        self._pack_key = "x"
+    def _ensure_flat(self): return self._flat
+    def grad_buckets(self): return self._flat.gflat[n_lora:], self._flat.gflat[:n_lora]
+eng = FakeEngine()
+ref = torch.stack([torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]).mean(0)
+sync = DataParallelSync(eng)
+sync.broadcast_parameters(0)
+assert torch.equal(eng._flat.flat, torch.zeros(n)) and eng._pack_key is None      # rank 0's parameters everywhere
+sync.decoder_ready()        # launched from inside backward once the decoder gradients exist
+sync.finish()               # LoRA bucket + wait + average
+assert torch.allclose(eng._flat.gflat, ref, atol=1e-6)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_data_parallel_sync(tmp_path):
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
