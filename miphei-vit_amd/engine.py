@@ -596,13 +596,6 @@ class HipEngine:
             raise NotImplementedError("training a fully unfrozen encoder is outside the MIPHEI-ViT (LoRA) hot path")
         w, pk, convs = sv.w, sv.pk, sv.convs
         B, D, M = w.B, c.D, w.M
-        # Weight-gradient GEMMs (TN kernels: conv dW, LoRA dA/dB) are off the critical path of the backward chain:
-        # they go to a side HIP stream and fill the CUs the persistent dgrad GEMMs leave idle in their tails.
-        main = torch.cuda.current_stream()
-        if getattr(self, "_side", None) is None or self._side.device != main.device:
-            self._side = torch.cuda.Stream(device=main.device)
-        side = self._side
-        side.wait_stream(main)
         S, s1, s2, s3, G = w.res
         dev = dY.device
         Mp = B * S * S
@@ -635,11 +628,7 @@ class HipEngine:
             bn = convs[i].bn
             ops.bn_relu_bwd(dy_post, ld_post, w.pre_f[j], bp.scale, bp.shift, bp.mean, bp.rstd, pk.bn[i].w, w.stats_b[i],
                             fl.gview[id(bn.weight)], fl.gview[id(bn.bias)], w.dpre_f[j], Mo, cout, NSLOTS)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                self._wgrad(w, i, cat, r, cp, cp, r, 1, w.dpre_f[j], cout)
+            self._wgrad(w, i, cat, r, cp, cp, r, 1, w.dpre_f[j], cout)
             # dgrad into the concat-gradient buffer (fus3: only the 64 upsampled channels carry gradient)
             ncols = FUS_OUT[2] if j == 3 else cp
             dcat = w.dcat[j]
@@ -675,17 +664,12 @@ class HipEngine:
             ops.bn_relu_bwd(dsk, dsk.shape[-1], w.pre_c[i], bp.scale, bp.shift, bp.mean, bp.rstd, pk.bn[i].w, w.stats_b[i],
                             fl.gview[id(bn.weight)], fl.gview[id(bn.bias)], w.dpre_c[i], Mo, cout, NSLOTS)
             a, r_in, cin, ld = srcs[i]
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                self._wgrad(w, i, a, r_in, cin, ld, r_out, 2, w.dpre_c[i], cout)
+            self._wgrad(w, i, a, r_in, cin, ld, r_out, 2, w.dpre_c[i], cout)
             if i > 0:
                 tgt, _ = skip[i - 1]
                 ops.gemm(w.dpre_c[i], pk.wd[i], tgt, M=B * r_in * r_in, N=cin, amode=A_CONV3_T,
                          conv=(r_out, r_out, cout, cout, r_in, r_in, 2), ldc=tgt.shape[-1], flags=ACCUM_BF16)
         # conv weight gradients: dWt [(ky,kx,c_pad), cout] -> parameter layout [cout, cin, ky, kx]
-        main.wait_stream(side)
         for i, cv in enumerate(convs):
             cp, cin = pk.cin_pad[i], pk.cin[i]
             g = w.dWt[i].view(3, 3, cp, -1)[:, :, :cin].permute(3, 2, 0, 1)
@@ -700,7 +684,6 @@ class HipEngine:
         r_ = c.rank
         scale = c.Dh ** -0.5
         lsplit = max(1, min(512 // ((D + 127) // 128), (M + 255) // 256))
-        lora_done = None
         last = fz.blocks[c.L - 1]
         ops.layernorm_bwd(w.dtok, w.x_in[c.L], fz.nw, w.dx, last.ls2, w.dy, c.eps, accumulate=False)
         for l in range(c.L - 1, -1, -1):
@@ -711,29 +694,19 @@ class HipEngine:
             ops.layernorm_bwd(w.dh, w.x_mid[l], b.n2w, w.dx, b.ls1, w.dy, c.eps, accumulate=True)
             # attention branch: dy = ls1 * dx
             ops.gemm(w.dy, b.t.wproj, w.do)
-            if lora_done is not None:
-                main.wait_event(lora_done)  # previous layer's LoRA gradients are done reading dqkv / dt
             ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, w.dqkv, B, c.ntok, c.H, c.Dh, scale)
             dq, dv = w.dqkv, w.dqkv.view(-1)[2 * D:]
             ops.skinny_xw(dq, pk.Bq16[l], w.dt, ldx=3 * D, ldo=2 * r_, M=M)                    # dt_q = dq @ (a B_q)^T
             ops.skinny_xw(dv, pk.Bv16[l], w.dt.view(-1)[r_:], ldx=3 * D, ldo=2 * r_, M=M)      # dt_v = dv @ (a B_v)^T
             t = w.t[l]
-            # LoRA weight gradients on the TN MFMA GEMM: dB = t^T dq (rows of B), dA = (dt^T h)^T (columns of A).
-            # Side stream; dqkv / dt are reused by the next layer, so its attention backward waits for this event.
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                ops.gemm_tn(t, dq, fl.dBq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
-                ops.gemm_tn(t.view(-1)[r_:], dv, fl.dBv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
-                ops.gemm_tn(w.dt, w.h1[l], fl.dAq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
-                ops.gemm_tn(w.dt.view(-1)[r_:], w.h1[l], fl.dAv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
-                lora_done = torch.cuda.Event()
-                lora_done.record(side)
+            # LoRA weight gradients on the TN MFMA GEMM: dB = t^T dq (rows of B), dA = (dt^T h)^T (columns of A)
+            ops.gemm_tn(t, dq, fl.dBq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
+            ops.gemm_tn(t.view(-1)[r_:], dv, fl.dBv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
+            ops.gemm_tn(w.dt, w.h1[l], fl.dAq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
+            ops.gemm_tn(w.dt.view(-1)[r_:], w.h1[l], fl.dAv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
             if l > 0:
                 ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
                 ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)
-        main.wait_stream(side)
         if c.alpha != 1.0:
             fl.dBq.mul_(c.alpha)
             fl.dBv.mul_(c.alpha)
