@@ -452,7 +452,12 @@ class HipEngine:
 
     def _bn(self, w, i, pk, conv_mod, count, bn_train):
         bp, bn = w.bnp[i], conv_mod.bn
-        ops.bn_finalize(w.stats_f[i], pk.bn[i].w, pk.bn[i].b, bn.running_mean, bn.running_var, bp.scale, bp.shift,
+        rm, rv = bn.running_mean, bn.running_var
+        if rm.dtype != torch.float32:  # .half() / .bfloat16() inference models: the kernels read f32 statistics
+            if bn_train:
+                raise RuntimeError("train-mode BatchNorm needs fp32 running statistics (model.float())")
+            rm, rv = rm.float(), rv.float()
+        ops.bn_finalize(w.stats_f[i], pk.bn[i].w, pk.bn[i].b, rm, rv, bp.scale, bp.shift,
                         bp.mean, bp.rstd, pk.bn[i].w.numel(), NSLOTS, count, BN_EPS, BN_MOM, bn_train)
 
     def _decoder_fwd(self, w, x, bn_train, pk, convs):

@@ -146,3 +146,17 @@ def test_512_tiles_ragged_tokens():
         out = model(x.cuda()).cpu()
         ref = generator_forward(p, x, cfg, 3, training=False)
     assert float(_chan_rel_mse(out, ref).max()) < REL_MSE
+
+
+def test_half_precision_eval_convention():
+    """evaluation scripts of the reference call generator.eval().cuda().half() and feed x.half() (eval_orion.py:191,214):
+    the engine accepts such a model (weights are re-packed to bf16 operands) and returns the input dtype."""
+    from oracle import generator_forward, synth_batch
+    cfg, p, model = _load("tiny_swiglu", 128, 3, 6)
+    model = model.eval().half()
+    x, _ = synth_batch(6, 2, 128, 3)
+    with torch.no_grad():
+        out = model(x.cuda().half())
+        ref = generator_forward(p, x, cfg, 3, training=False)
+    assert out.dtype == torch.float16
+    assert float(_chan_rel_mse(out.float().cpu(), ref).max()) < 2e-3   # fp16-rounded parameters + bf16 compute
