@@ -167,12 +167,14 @@ MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x,
                                  void* ET /*bf16 [NH*9, M]*/, float* dG /*[M,16]*/, float* dXc /*[M,32]*/,
                                  float* db3 /*[64 slots][32] partial sums, zeroed; sum over slots*/, int B,
                                  int H, int W, int NH, mvit_stream_t stream);
+/* scratch for mvit_heads_gate_bwd: per-block partial sums of the reduction pass + the apply-pass coefficients */
+MVIT_API long long mvit_heads_gate_bwd_scratch_bytes(void);
 MVIT_API int mvit_heads_gate_bwd(const void* x, const void* G, const float* dG, const float* dXc, const float* W1,
                                  const float* b1, const float* scale, const float* shift, const float* mean,
                                  const float* rstd, const float* gamma, const float* W2, const double* mom_sum,
-                                 double* red /*[nslots][NH*16][36], zeroed*/, float* coef /*[NH*16][2]*/, float* dW1,
-                                 float* dgamma, float* dbeta, float* dW2, float* db2, void* dF /*bf16 [M,32]*/, long long M,
-                                 int NH, int nslots, double count, mvit_stream_t stream);
+                                 void* scratch, long long scratch_bytes, float* dW1, float* dgamma, float* dbeta,
+                                 float* dW2, float* db2, void* dF /*bf16 [M,32]*/, long long M, int NH, double count,
+                                 mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- loss / optimiser */
 /* WeightedMSELoss (src/loss.py:47-57): loss_acc += sum_c w_c sum (p-t)^2 (caller multiplies by lambda/(C*B*HW));

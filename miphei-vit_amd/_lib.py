@@ -64,7 +64,8 @@ SIGNATURES = {
     "mvit_heads_gate_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp],
     "mvit_heads_conv_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_heads_conv_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
-    "mvit_heads_gate_bwd": [vp] * 21 + [ll, ci, ci, cd, vp],
+    "mvit_heads_gate_bwd_scratch_bytes": [],
+    "mvit_heads_gate_bwd": [vp] * 14 + [ll] + [vp] * 6 + [ll, ci, cd, vp],
     "mvit_wmse_fwd_bwd": [vp, vp, vp, vp, vp, ci, ci, ll, cf, vp],
     "mvit_sqnorm": [vp, vp, ll, vp],
     "mvit_u8_nhwc_to_f32_nchw": [vp, vp, vp, vp, ci, ci, ll, vp],
@@ -92,7 +93,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = C.c_longlong if name.endswith("_bytes") else C.c_int
         _lib = handle
     return _lib
 

@@ -3,12 +3,12 @@
 // Reference: AttentionBlock / SegmentationHead, src/generators/unet.py:407-438, instantiated once per
 // marker at src/generators/mipheivit.py:198-205 and run at :213-218 (9 op launches per head, the
 // 32-channel map re-read 16 times).  Here the map is read once per stage:
-//   moments   : sum x and sum x x^T over all pixels  -> the train-mode BatchNorm statistics of every
-//               head's 1x1 conv output follow analytically (mean = w.mu + b, var = w^T Cov w)
-//   gate      : g[p,h] = sigmoid(w2 . relu(BN(W1 x + b1)) + b2) for all heads, one thread per pixel
+//   moments   : sum x and sum x x^T over all pixels (MFMA on transposed tiles) -> the train-mode BatchNorm statistics
+//               of every head's 1x1 conv output follow analytically (mean = w.mu + b, var = w^T Cov w)
+//   gate      : g[p,h] = sigmoid(w2 . relu(BN(W1 x + b1)) + b2) for all heads: the 256 stacked gate channels of a
+//               32-pixel tile are one MFMA block chain per wave (bf16 operands, fp32 accumulate)
 //   conv      : y[p,h] = tanh(b3 + sum_{3x3} W3[h] . (x*g_h)), one thread per pixel, NCHW f32 output
-// and the matching backward passes.  VALU kernels with LDS-broadcast weights; HBM traffic is the
-// 32-channel map plus the 16-channel gate / output.
+// and the matching backward passes.  HBM traffic is the 32-channel map plus the 16-channel gate / output.
 #include "common.hpp"
 #include "../../include/miphei_hip.h"
 
@@ -45,50 +45,172 @@ __device__ __forceinline__ void load_g16(const bf16_t* __restrict__ p, float (&g
   }
 }
 
-// ------------------------------------------------------------------ moments: sum x (32), sum x x^T (32x32)
+// ------------------------------------------------------------------ MFMA building blocks of the gate kernels
+// v_mfma_f32_32x32x16_bf16 operand layouts (lane l: l31 = l & 31, half = l >> 5):
+//   A[32 x 16]: row l31, K = 8*half + e (e = 0..7);  B[16 x 32]: col l31, K = 8*half + e;
+//   D[32 x 32]: col l31, row acc_row(j, half) for accumulator register j = 0..15.
+// A D block is chained into the next MFMA as a K operand without leaving registers: registers j = 8*ks + e of a lane
+// become its eight K slots of k-step ks, i.e. K index 8*half + e stands for row acc_row(8*ks + e, half); the other
+// operand is built with the same permutation.
+typedef short v4s __attribute__((ext_vector_type(4)));
+union Frag {
+  bf16x8 v;
+  uint32_t u[4];
+  uint4 q;
+  v4s h[2];
+};
+constexpr int NBLK = MAXH * HC / 32;  // 32-channel blocks of the stacked gate channels (2 heads per block)
+
+__device__ __forceinline__ int acc_row(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }
+__device__ __forceinline__ bf16x8 frag8(const float* f) {
+  Frag r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r.u[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+  return r.v;
+}
+__device__ __forceinline__ bf16x8 frag_lo(uint32_t w0) {  // K slots 0,1 from one packed word, the rest zero
+  Frag r;
+  r.u[0] = w0, r.u[1] = 0u, r.u[2] = 0u, r.u[3] = 0u;
+  return r.v;
+}
+// fp32 value as a (hi, lo) bf16 pair packed into one word: hi + lo carries ~16 mantissa bits through a bf16 MFMA
+__device__ __forceinline__ uint32_t split_bf(float v) {
+  const uint32_t hi = pack2bf(v, 0.f) & 0xffffu;
+  const float rem = v - __uint_as_float(hi << 16);
+  return hi | (pack2bf(rem, 0.f) << 16);
+}
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) z[j] = 0.f;
+  return z;
+}
+// transposed 32x32 bf16 tile (64-byte rows) as a K operand: slot e of k-step ks <-> tile row acc_row(8*ks+e, half), col l31
+__device__ __forceinline__ bf16x8 tile_T_frag(const char* tile, int ks, int lane) {
+  const int i = lane & 15, half = lane >> 5;
+  const char* p = tile + (ks * 16 + 4 * half + (i >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
+  Frag r;
+  r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
+  r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 8 * 64));
+  return r.v;
+}
+// the two 16-byte pieces of pixel row p this lane feeds as a K operand (channel = 16*ks + 8*half + e)
+__device__ __forceinline__ void load_x_frags(const bf16_t* __restrict__ x, long long p, bool live, int half, Frag& x0, Frag& x1) {
+  if (live) {
+    const uint4* r = (const uint4*)(x + (size_t)p * XC);
+    x0.q = r[half];
+    x1.q = r[2 + half];
+  } else {
+    x0.q = make_uint4(0, 0, 0, 0);
+    x1.q = make_uint4(0, 0, 0, 0);
+  }
+}
+// (hi, lo) bf16 pair of operands for eight fp32 values: hi + lo keeps ~16 mantissa bits through the bf16 MFMA, which
+// pins the relu mask sign(a) to the fp32 result
+__device__ __forceinline__ void frag8_split(const float* f, bf16x8& hi, bf16x8& lo) {
+  float h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = __uint_as_float(pack2bf(f[e], 0.f) << 16);
+    l[e] = f[e] - h[e];
+  }
+  hi = frag8(h);
+  lo = frag8(l);
+}
+// stacked 1x1-conv weights with the BatchNorm scale folded in, as the operand indexed by (channel = lane, K = x channel)
+// (hi part in registers, lo part in a lane-indexed LDS table written by wave 0)
+__device__ __forceinline__ void load_w1s(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, int nch, int lane, bool write_lo,
+                                         bf16x8 (&w)[NBLK][2], bf16x8 (*wlo)[64], float (&bias)[NBLK]) {
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const int ch = blk * 32 + l31;
+    const bool ok = ch < nch;
+    const float sc = ok ? scale[ch] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = ok ? W1[(size_t)ch * XC + ks * 16 + half * 8 + e] * sc : 0.f;
+      bf16x8 lo;
+      frag8_split(f, w[blk][ks], lo);
+      if (write_lo) wlo[2 * blk + ks][lane] = lo;
+    }
+    bias[blk] = ok ? b1[ch] * sc + shift[ch] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ moments: sum x (32), sum x x^T (32x32) on MFMA
 __global__ __launch_bounds__(256) void moments_kernel(const bf16_t* __restrict__ x, double* __restrict__ mom, long long M,
                                                       int nslots) {
-  __shared__ float xs[64][XC + 1];
-  const int tid = threadIdx.x, i = tid >> 3, j0 = (tid & 7) * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, s = 0.f;
-  for (long long r0 = (long long)blockIdx.x * 64; r0 < M; r0 += (long long)gridDim.x * 64) {
-    __syncthreads();
-    for (int e = tid; e < 64 * XC; e += 256) {
-      const int r = e >> 5, c = e & 31;
-      xs[r][c] = (r0 + r < M) ? bf2f(x[(size_t)(r0 + r) * XC + c]) : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < 64; ++r) {
-      const float a = xs[r][i];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += a * xs[r][j0 + q];
-      if (tid < XC) s += xs[r][tid];
-    }
+  __shared__ __attribute__((aligned(16))) char tiles[4][2048];
+  __shared__ float red[NMOM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  for (int e = threadIdx.x; e < NMOM; e += 256) red[e] = 0.f;
+  __syncthreads();
+  char* tile = tiles[wave];
+  Frag ones;
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+  f32x16 acc = zero16(), s = zero16();
+  const long long ntile = (M + 31) / 32;
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
+    const long long p = t * 32 + l31;
+    Frag x0, x1;
+    load_x_frags(x, p, p < M, half, x0, x1);
+    *(uint4*)(tile + l31 * 64 + half * 16) = x0.q;
+    *(uint4*)(tile + l31 * 64 + 32 + half * 16) = x1.q;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bf16x8 f0 = tile_T_frag(tile, 0, lane), f1 = tile_T_frag(tile, 1, lane);
+    acc = mfma(f0, f0, acc);
+    acc = mfma(f1, f1, acc);
+    s = mfma(f0, ones.v, s);
+    s = mfma(f1, ones.v, s);
+    __builtin_amdgcn_wave_barrier();
   }
-  double* o = mom + (size_t)(blockIdx.x % nslots) * NMOM;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) atomicAdd(o + XC + i * XC + j0 + q, (double)acc[q]);
-  if (tid < XC) atomicAdd(o + tid, (double)s);
+  for (int j = 0; j < 16; ++j) {
+    atomicAdd(&red[XC + acc_row(j, half) * XC + l31], acc[j]);
+    if (l31 == 0) atomicAdd(&red[acc_row(j, half)], s[j]);
+  }
+  __syncthreads();
+  double* o = mom + (size_t)(blockIdx.x % nslots) * NMOM;
+  for (int e = threadIdx.x; e < NMOM; e += 256) atomicAdd(o + e, (double)red[e]);
 }
 
 // ------------------------------------------------------------------ BN statistics of every gate channel from the moments
-__global__ __launch_bounds__(256) void bn_from_moments_kernel(const double* __restrict__ mom, const float* __restrict__ W1,
-                                                              const float* __restrict__ b1, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ rmean,
-                                                              float* __restrict__ rvar, float* __restrict__ scale,
-                                                              float* __restrict__ shift, float* __restrict__ mean_o,
-                                                              float* __restrict__ rstd_o, double* __restrict__ mom_sum,
-                                                              int NCH, int nslots, double count, float eps, float momentum,
-                                                              int training) {
+__global__ __launch_bounds__(1024) void bn_from_moments_kernel(const double* __restrict__ mom, const float* __restrict__ W1,
+                                                               const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ rmean,
+                                                               float* __restrict__ rvar, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float* __restrict__ mean_o,
+                                                               float* __restrict__ rstd_o, double* __restrict__ mom_sum,
+                                                               int NCH, int nslots, double count, float eps, float momentum,
+                                                               int training) {
   __shared__ double ms[NMOM];
+  __shared__ double cov[XC * XC];
   const int ch = threadIdx.x;
   if (training) {
-    for (int e = threadIdx.x; e < NMOM; e += 256) {
-      double s = 0.;
-      for (int k = 0; k < nslots; ++k) s += mom[(size_t)k * NMOM + e];
+    for (int e = threadIdx.x; e < NMOM; e += 1024) {
+      double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+      int k = 0;
+      for (; k + 4 <= nslots; k += 4) {
+        s0 += mom[(size_t)k * NMOM + e];
+        s1 += mom[(size_t)(k + 1) * NMOM + e];
+        s2 += mom[(size_t)(k + 2) * NMOM + e];
+        s3 += mom[(size_t)(k + 3) * NMOM + e];
+      }
+      for (; k < nslots; ++k) s0 += mom[(size_t)k * NMOM + e];
+      const double s = (s0 + s1) + (s2 + s3);
       ms[e] = s;
       if (mom_sum) mom_sum[e] = s;
+    }
+    __syncthreads();
+    {
+      const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
+      cov[threadIdx.x] = ms[XC + j * XC + k] / count - (ms[j] / count) * (ms[k] / count);
     }
     __syncthreads();
   }
@@ -100,9 +222,11 @@ __global__ __launch_bounds__(256) void bn_from_moments_kernel(const double* __re
     for (int k = 0; k < XC; ++k) wm += (double)w[k] * ms[k] / count;
     mean = wm + b1[ch];
     double v = 0.;
+#pragma unroll 1
     for (int j = 0; j < XC; ++j) {
       double row = 0.;
-      for (int k = 0; k < XC; ++k) row += (double)w[k] * (ms[XC + j * XC + k] / count - (ms[j] / count) * (ms[k] / count));
+#pragma unroll 4
+      for (int k = 0; k < XC; ++k) row += (double)w[k] * cov[j * XC + k];
       v += (double)w[j] * row;
     }
     var = v < 0. ? 0. : v;
@@ -121,52 +245,70 @@ __global__ __launch_bounds__(256) void bn_from_moments_kernel(const double* __re
   if (rstd_o) rstd_o[ch] = (float)rstd;
 }
 
-// ------------------------------------------------------------------ gate forward (thread per pixel)
-__global__ __launch_bounds__(256) void gate_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ W1,
-                                                       const float* __restrict__ b1, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ W2,
-                                                       const float* __restrict__ b2, bf16_t* __restrict__ G, long long M,
-                                                       int NH) {
-  __shared__ __attribute__((aligned(16))) float w1s[MAXH * HC * XC];
-  __shared__ float b1s[MAXH * HC], w2s[MAXH * HC], b2s[MAXH];
-  const int nch = NH * HC;
-  for (int e = threadIdx.x; e < nch * XC; e += 256) w1s[e] = W1[e] * scale[e >> 5];  // BN folded into the 1x1 conv
-  for (int e = threadIdx.x; e < nch; e += 256) {
-    b1s[e] = b1[e] * scale[e] + shift[e];
-    w2s[e] = W2[e];
-  }
-  if (threadIdx.x < NH) b2s[threadIdx.x] = b2[threadIdx.x];
-  __syncthreads();
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < M; p += (long long)gridDim.x * 256) {
-    float xv[XC];
-    load_x32(x + (size_t)p * XC, xv);
-    float g[MAXH];
+// ------------------------------------------------------------------ gate forward
+// per 32-pixel tile and wave: a[ch,px] = W1s x + bias (3 MFMAs per 32 channels, the bias rides on a ones operand),
+// relu in registers, psi[h,px] = sum_ch w2[ch] relu(a) as a second MFMA on the chained block, sigmoid, 16-byte store.
+__global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ W1,
+                                                          const float* __restrict__ b1, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ W2,
+                                                          const float* __restrict__ b2, bf16_t* __restrict__ G, long long M,
+                                                          int NH) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int nch = NH * HC, nblk = (nch + 31) / 32;
+  __shared__ bf16x8 w2s[NBLK * 2][64];  // psi operand, lane-indexed (read back as conflict-free 16-byte rows)
+  __shared__ bf16x8 wAl[NBLK * 2][64];  // lo parts of W1s
+  bf16x8 wA[NBLK][2];
+  float biasf[NBLK];
+  uint32_t wbias[NBLK];
+  load_w1s(W1, b1, scale, shift, nch, lane, wave == 0, wA, wAl, biasf);
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) g[h] = 0.f;
-    for (int h = 0; h < NH; ++h) {
-      float psi = b2s[h];
-#pragma unroll 4
-      for (int c = 0; c < HC; ++c) {
-        const float4* w = (const float4*)(w1s + (h * HC + c) * XC);
-        float a = b1s[h * HC + c];
+  for (int blk = 0; blk < NBLK; ++blk) wbias[blk] = half == 0 ? split_bf(biasf[blk]) : 0u;
+  for (int f = wave; f < NBLK * 2; f += 4) {  // row l31 of the psi operand selects head f = 2*blk + ks
+    float v[8];
 #pragma unroll
-        for (int k = 0; k < XC / 4; ++k) {
-          const float4 ww = w[k];
-          a += ww.x * xv[4 * k] + ww.y * xv[4 * k + 1] + ww.z * xv[4 * k + 2] + ww.w * xv[4 * k + 3];
-        }
-        psi += w2s[h * HC + c] * fmaxf(a, 0.f);
-      }
-      const float gv = sigmoidf_(psi);
-#pragma unroll
-      for (int hh = 0; hh < MAXH; ++hh)
-        if (hh == h) g[hh] = gv;
+    for (int e = 0; e < 8; ++e) {
+      const int c = (f >> 1) * 32 + acc_row(8 * (f & 1) + e, half);
+      v[e] = (l31 == f && c < nch) ? W2[c] : 0.f;
     }
-    uint4 o[2];
-    uint32_t* ou = (uint32_t*)o;
+    w2s[f][lane] = frag8(v);
+  }
+  __syncthreads();
+  const bf16x8 ones = frag_lo(half == 0 ? 0x3f803f80u : 0u);
+  float b2r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ou[j] = pack2bf(g[2 * j], g[2 * j + 1]);
-    ((uint4*)(G + (size_t)p * MAXH))[0] = o[0];
-    ((uint4*)(G + (size_t)p * MAXH))[1] = o[1];
+  for (int j = 0; j < 8; ++j) b2r[j] = acc_row(j, half) < NH ? b2[acc_row(j, half)] : 0.f;
+
+  const long long ntile = (M + 31) / 32;
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
+    const long long p = t * 32 + l31;
+    const bool live = p < M;
+    Frag x0, x1;
+    load_x_frags(x, p, live, half, x0, x1);
+    f32x16 psi = zero16();
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+      if (blk < nblk) {
+        f32x16 a = mfma(wA[blk][0], x0.v, zero16());
+        a = mfma(wA[blk][1], x1.v, a);
+        a = mfma(wAl[2 * blk][lane], x0.v, a);
+        a = mfma(wAl[2 * blk + 1][lane], x1.v, a);
+        a = mfma(frag_lo(wbias[blk]), ones, a);
+        float r[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r[j] = fmaxf(a[j], 0.f);
+        psi = mfma(w2s[2 * blk][lane], frag8(r), psi);
+        psi = mfma(w2s[2 * blk + 1][lane], frag8(r + 8), psi);
+      }
+    }
+    // psi rows (heads) of this lane: acc_row(j, half), j < 8  ->  heads 4*half+{0..3} and 8+4*half+{0..3}
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = acc_row(j, half) < NH ? sigmoidf_(psi[j] + b2r[j]) : 0.f;
+    if (live) {
+      bf16_t* o = G + (size_t)p * MAXH + 4 * half;
+      *(uint2*)o = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
+      *(uint2*)(o + 8) = make_uint2(pack2bf(g[4], g[5]), pack2bf(g[6], g[7]));
+    }
   }
 }
 
@@ -300,184 +442,323 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__
   }
 }
 
-// ------------------------------------------------------------------ gate backward, reduction pass (thread per gate channel)
-// per channel ch=(h,c): Sb = sum da, Sg = sum da*that, Z[k] = sum (da*gamma) x_k, dw2 = sum dpsi*r, (c==0) db2 = sum dpsi
-constexpr int GR_ROWS = 32;
-constexpr int GR_OUT = 4 + XC;  // Sb, Sg, dw2, db2, Z[32]
-__global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G,
-                                                              const float* __restrict__ dG, const float* __restrict__ W1,
-                                                              const float* __restrict__ b1, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                              const float* __restrict__ W2, double* __restrict__ red,
-                                                              long long M, int NH, int nslots) {
-  __shared__ __attribute__((aligned(16))) float xs[GR_ROWS][XC];
-  __shared__ float dps[GR_ROWS][MAXH];
-  const int ch = threadIdx.x, nch = NH * HC;
-  const bool act = ch < nch;
-  const int h = act ? ch / HC : 0;
-  float w[XC];
-#pragma unroll
-  for (int k = 0; k < XC; ++k) w[k] = act ? W1[(size_t)ch * XC + k] : 0.f;
-  const float bb = act ? b1[ch] : 0.f, sc = act ? scale[ch] : 0.f, sh = act ? shift[ch] : 0.f;
-  const float mu = act ? mean[ch] : 0.f, rs = act ? rstd[ch] : 0.f, gm = act ? gamma[ch] : 0.f, w2 = act ? W2[ch] : 0.f;
-  float Sb = 0.f, Sg = 0.f, dw2 = 0.f, db2 = 0.f, Z[XC];
-#pragma unroll
-  for (int k = 0; k < XC; ++k) Z[k] = 0.f;
-  for (long long r0 = (long long)blockIdx.x * GR_ROWS; r0 < M; r0 += (long long)gridDim.x * GR_ROWS) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < GR_ROWS * XC; e += 256) {
-      const int r = e >> 5, c = e & 31;
-      xs[r][c] = (r0 + r < M) ? bf2f(x[(size_t)(r0 + r) * XC + c]) : 0.f;
-    }
-    for (int e = threadIdx.x; e < GR_ROWS * MAXH; e += 256) {
-      const int r = e >> 4, hh = e & 15;
-      float v = 0.f;
-      if (r0 + r < M && hh < NH) {
-        const float gv = bf2f(G[(size_t)(r0 + r) * MAXH + hh]);
-        v = dG[(size_t)(r0 + r) * MAXH + hh] * gv * (1.f - gv);
-      }
-      dps[r][hh] = v;
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll 2
-      for (int r = 0; r < GR_ROWS; ++r) {
-        const float4* xr = (const float4*)xs[r];
-        float u = bb;
-#pragma unroll
-        for (int k = 0; k < XC / 4; ++k) {
-          const float4 xx = xr[k];
-          u += w[4 * k] * xx.x + w[4 * k + 1] * xx.y + w[4 * k + 2] * xx.z + w[4 * k + 3] * xx.w;
-        }
-        const float a = u * sc + sh;
-        const float dpsi = dps[r][h];
-        const float da = a > 0.f ? dpsi * w2 : 0.f;
-        Sb += da;
-        Sg += da * (u - mu) * rs;
-        dw2 += dpsi * fmaxf(a, 0.f);
-        db2 += dpsi;
-        const float dt = da * gm;
-#pragma unroll
-        for (int k = 0; k < XC / 4; ++k) {
-          const float4 xx = xr[k];
-          Z[4 * k] += dt * xx.x;
-          Z[4 * k + 1] += dt * xx.y;
-          Z[4 * k + 2] += dt * xx.z;
-          Z[4 * k + 3] += dt * xx.w;
-        }
-      }
-    }
-  }
-  if (act) {
-    double* o = red + ((size_t)(blockIdx.x % nslots) * nch + ch) * GR_OUT;
-    atomicAdd(o + 0, (double)Sb);
-    atomicAdd(o + 1, (double)Sg);
-    atomicAdd(o + 2, (double)dw2);
-    atomicAdd(o + 3, (double)db2);
-#pragma unroll
-    for (int k = 0; k < XC; ++k) atomicAdd(o + 4 + k, (double)Z[k]);
-  }
-}
+// ------------------------------------------------------------------ gate backward
+// With dr[p,ch] = relu'(a[p,ch]) * dpsi[p,head(ch)], every sum the BatchNorm/conv backward needs is linear in
+//   Zr[ch,k] = sum_p dr[p,ch] x[p,k],   Sr[ch] = sum_p dr[p,ch],   db2[h] = sum_p dpsi[p,h]
+// (u = W1 x + b1 is affine in x), so the reduction pass is two chained MFMAs per 32 channels and the per-channel
+// algebra moves to a tiny finalize kernel.  The apply pass splits du[p,ch] = K1 dr + K2 u + K3 into the masked part
+// (MFMA against K1*W1) and the affine part x Q + r with Q = W1^T diag(K2) W1 (one 32x32 matrix for all channels).
+constexpr int RED_Z = MAXH * HC * XC;            // Zr
+constexpr int RED_N = RED_Z + MAXH * HC + MAXH;  // + Sr + db2
+constexpr int RED_BLOCKS = 256;                  // partial sums written by the reduction pass
+// scratch layout (floats): part[RED_BLOCKS][RED_N] | coef[256][4] (K1, K2, K2*b1+K3, -) | Q[32][32] | r[32]
+constexpr size_t SCR_COEF = (size_t)RED_BLOCKS * RED_N;
+constexpr size_t SCR_Q = SCR_COEF + MAXH * HC * 4;
+constexpr size_t SCR_R = SCR_Q + XC * XC;
+constexpr size_t SCR_FLOATS = SCR_R + XC;
 
-// finalize: parameter gradients + the two per-channel coefficients of the BN backward
-__global__ __launch_bounds__(256) void gate_bwd_finalize_kernel(const double* __restrict__ red, const double* __restrict__ mom_sum,
-                                                                const float* __restrict__ W1, const float* __restrict__ b1,
-                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                const float* __restrict__ gamma, float* __restrict__ dW1,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                float* __restrict__ dW2, float* __restrict__ db2,
-                                                                float* __restrict__ coef, int NH, int nslots, double count) {
-  const int ch = threadIdx.x, nch = NH * HC;
-  if (ch >= nch) return;
-  double s[GR_OUT];
-  for (int k = 0; k < GR_OUT; ++k) {
-    double a = 0.;
-    for (int sl = 0; sl < nslots; ++sl) a += red[((size_t)sl * nch + ch) * GR_OUT + k];
-    s[k] = a;
+__global__ __launch_bounds__(512, 1) void gate_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G,
+                                                                 const float* __restrict__ dG, const float* __restrict__ W1,
+                                                                 const float* __restrict__ b1, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ part,
+                                                                 long long M, int NH) {
+  // eight waves = four pixel streams x two channel groups (128 gate channels each, so the Zr accumulators stay at
+  // 64 registers); per wave: x tile (2 KB) + dpsi^T tile [16 heads][32 px] f32 (2 KB); the same LDS is reused for
+  // the cross-wave reduction at the end
+  constexpr int WB = NBLK / 2;
+  __shared__ __attribute__((aligned(16))) char sm[NBLK * 16 * 64 * 4 + NBLK * 64 * 4 + MAXH * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int cg = wave & 1, stream = wave >> 1;
+  const int nch = NH * HC, nblk = (nch + 31) / 32;
+  char* xt = sm + wave * 4096;
+  float* dps = (float*)(xt + 2048);
+  bf16x8 wB[WB][2], wBl[WB][2];
+  float thr[WB];
+#pragma unroll
+  for (int b = 0; b < WB; ++b) {
+    const int ch = (cg * WB + b) * 32 + l31;
+    const bool ok = ch < nch;
+    const float sc = ok ? scale[ch] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = ok ? W1[(size_t)ch * XC + ks * 16 + half * 8 + e] * sc : 0.f;
+      frag8_split(f, wB[b][ks], wBl[b][ks]);
+    }
+    thr[b] = ok ? -(b1[ch] * sc + shift[ch]) : 0.f;  // a > 0  <=>  W1s x > -bias
   }
-  const double Sb = s[0], Sg = s[1], gm = gamma[ch], rs = rstd[ch], mu = mean[ch];
-  const double c1 = gm * Sb / count, c2 = gm * Sg / count;
-  coef[2 * ch] = (float)c1;
-  coef[2 * ch + 1] = (float)c2;
-  dgamma[ch] += (float)Sg;
-  dbeta[ch] += (float)Sb;
-  dW2[ch] += (float)s[2];
-  if ((ch % HC) == 0) db2[ch / HC] += (float)s[3];
-  const float* w = W1 + (size_t)ch * XC;
-  for (int k = 0; k < XC; ++k) {
-    double wm2 = 0.;
-    for (int j = 0; j < XC; ++j) wm2 += (double)w[j] * mom_sum[XC + j * XC + k];
-    const double tx = rs * (wm2 + ((double)b1[ch] - mu) * mom_sum[k]);  // sum_p that_p x_p[k]
-    dW1[(size_t)ch * XC + k] += (float)(rs * (s[4 + k] - c1 * mom_sum[k] - c2 * tx));
-  }
-}
+  f32x16 Z[WB];
+  float sr[WB], dbh[8];
+#pragma unroll
+  for (int b = 0; b < WB; ++b) Z[b] = zero16(), sr[b] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dbh[e] = 0.f;
 
-// apply pass (thread per pixel): dF3[p,k] = dXc[p,k] + sum_{h,c} du[h,c] W1[h,c,k]
-__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G,
-                                                             const float* __restrict__ dG, const float* __restrict__ dXc,
-                                                             const float* __restrict__ W1, const float* __restrict__ b1,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             const float* __restrict__ gamma, const float* __restrict__ W2,
-                                                             const float* __restrict__ coef, bf16_t* __restrict__ dF,
-                                                             long long M, int NH) {
-  __shared__ __attribute__((aligned(16))) float w1s[MAXH * HC * XC];
-  __shared__ float ps[MAXH * HC][8];  // b1, scale, shift, mean, rstd, gamma, w2, pad
-  __shared__ float cs[MAXH * HC][2];
-  const int nch = NH * HC;
-  for (int e = threadIdx.x; e < nch * XC; e += 256) w1s[e] = W1[e];
-  for (int e = threadIdx.x; e < nch; e += 256) {
-    ps[e][0] = b1[e], ps[e][1] = scale[e], ps[e][2] = shift[e], ps[e][3] = mean[e], ps[e][4] = rstd[e], ps[e][5] = gamma[e];
-    ps[e][6] = W2[e];
-    cs[e][0] = coef[2 * e], cs[e][1] = coef[2 * e + 1];
+  const long long ntile = (M + 31) / 32;
+  if (cg * WB < nblk) {
+    for (long long t = (long long)blockIdx.x * 4 + stream; t < ntile; t += (long long)gridDim.x * 4) {
+      const long long p = t * 32 + l31;
+      const bool live = p < M;
+      Frag x0, x1;
+      load_x_frags(x, p, live, half, x0, x1);
+      float dpsi[8];
+      if (live) {
+        const uint4 gq = *(const uint4*)(G + (size_t)p * MAXH + half * 8);
+        const float4 d0 = *(const float4*)(dG + (size_t)p * MAXH + half * 8), d1 = *(const float4*)(dG + (size_t)p * MAXH + half * 8 + 4);
+        const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w};
+        const float dg[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = __uint_as_float((e & 1) ? (gu[e >> 1] & 0xffff0000u) : (gu[e >> 1] << 16));
+          dpsi[e] = (half * 8 + e < NH) ? dg[e] * g * (1.f - g) : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dpsi[e] = 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      *(uint4*)(xt + l31 * 64 + half * 16) = x0.q;
+      *(uint4*)(xt + l31 * 64 + 32 + half * 16) = x1.q;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dbh[e] += dpsi[e];
+        dps[(half * 8 + e) * 32 + l31] = dpsi[e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const bf16x8 xT0 = tile_T_frag(xt, 0, lane), xT1 = tile_T_frag(xt, 1, lane);
+#pragma unroll
+      for (int b = 0; b < WB; ++b) {
+        const int blk = cg * WB + b;
+        if (blk < nblk) {
+          f32x16 a = mfma(x0.v, wB[b][0], zero16());  // a[px, ch]: col = channel l31 of the block, rows = pixels
+          a = mfma(x1.v, wB[b][1], a);
+          a = mfma(x0.v, wBl[b][0], a);
+          a = mfma(x1.v, wBl[b][1], a);
+          const float* dp = dps + (blk * 2 + (l31 >> 4)) * 32 + 4 * half;
+          float dr[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 d = *(const float4*)(dp + 8 * q);
+            dr[4 * q] = a[4 * q] > thr[b] ? d.x : 0.f;
+            dr[4 * q + 1] = a[4 * q + 1] > thr[b] ? d.y : 0.f;
+            dr[4 * q + 2] = a[4 * q + 2] > thr[b] ? d.z : 0.f;
+            dr[4 * q + 3] = a[4 * q + 3] > thr[b] ? d.w : 0.f;
+          }
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) s += dr[j];
+          sr[b] += s;
+          Z[b] = mfma(frag8(dr), xT0, Z[b]);  // Zr[ch, k]: rows = channels (chained), col = x channel l31
+          Z[b] = mfma(frag8(dr + 8), xT1, Z[b]);
+        }
+      }
+    }
+  }
+  // ---- block reduction of the waves' accumulators, then one partial row per block
+  float* zb = (float*)sm;                     // [NBLK][16][64]
+  float* sb = zb + NBLK * 16 * 64;            // [NBLK][64]
+  float* db = sb + NBLK * 64;                 // [MAXH]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dbh[e] += __shfl_xor(dbh[e], o, 64);
   }
   __syncthreads();
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < M; p += (long long)gridDim.x * 256) {
-    float xv[XC], g[MAXH], dx[XC];
-    load_x32(x + (size_t)p * XC, xv);
-    load_g16(G + (size_t)p * MAXH, g);
+  if (threadIdx.x < MAXH) db[threadIdx.x] = 0.f;
+  for (int w = 0; w < 4; ++w) {
+    if (stream == w) {
 #pragma unroll
-    for (int k = 0; k < XC / 4; ++k) {
-      const float4 t = ((const float4*)(dXc + (size_t)p * XC))[k];
-      dx[4 * k] = t.x, dx[4 * k + 1] = t.y, dx[4 * k + 2] = t.z, dx[4 * k + 3] = t.w;
-    }
-    for (int h = 0; h < NH; ++h) {
-      float gh = 0.f;
+      for (int b = 0; b < WB; ++b) {
+        const int blk = cg * WB + b;
 #pragma unroll
-      for (int hh = 0; hh < MAXH; ++hh)
-        if (hh == h) gh = g[hh];
-      const float dpsi = dG[(size_t)p * MAXH + h] * gh * (1.f - gh);
-#pragma unroll 2
-      for (int c = 0; c < HC; ++c) {
-        const int ch = h * HC + c;
-        const float4* w = (const float4*)(w1s + ch * XC);
-        float u = ps[ch][0];
-#pragma unroll
-        for (int k = 0; k < XC / 4; ++k) {
-          const float4 ww = w[k];
-          u += ww.x * xv[4 * k] + ww.y * xv[4 * k + 1] + ww.z * xv[4 * k + 2] + ww.w * xv[4 * k + 3];
+        for (int j = 0; j < 16; ++j) {
+          float* q = zb + (blk * 16 + j) * 64 + lane;
+          *q = (w == 0 ? 0.f : *q) + Z[b][j];
         }
-        const float a = u * ps[ch][1] + ps[ch][2];
-        const float dt = a > 0.f ? dpsi * ps[ch][6] * ps[ch][5] : 0.f;
-        const float th = (u - ps[ch][3]) * ps[ch][4];
-        const float du = ps[ch][4] * (dt - cs[ch][0] - th * cs[ch][1]);
-#pragma unroll
-        for (int k = 0; k < XC / 4; ++k) {
-          const float4 ww = w[k];
-          dx[4 * k] += du * ww.x;
-          dx[4 * k + 1] += du * ww.y;
-          dx[4 * k + 2] += du * ww.z;
-          dx[4 * k + 3] += du * ww.w;
-        }
+        float* q = sb + blk * 64 + lane;
+        *q = (w == 0 ? 0.f : *q) + sr[b];
       }
     }
-    uint4 o[4];
-    uint32_t* ou = (uint32_t*)o;
+    __syncthreads();
+  }
+  if (l31 == 0 && cg == 0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) ou[j] = pack2bf(dx[2 * j], dx[2 * j + 1]);
+    for (int e = 0; e < 8; ++e) atomicAdd(&db[half * 8 + e], dbh[e]);
+  }
+  __syncthreads();
+  float* o = part + (size_t)blockIdx.x * RED_N;
+  for (int e = threadIdx.x; e < NBLK * 16 * 64; e += 512) {
+    const int ln = e & 63, j = (e >> 6) & 15, blk = e >> 10;
+    o[(blk * 32 + acc_row(j, ln >> 5)) * XC + (ln & 31)] = zb[e];
+  }
+  if (threadIdx.x < MAXH * HC) {
+    const float* q = sb + (threadIdx.x >> 5) * 64 + (threadIdx.x & 31);
+    o[RED_Z + threadIdx.x] = q[0] + q[32];
+  }
+  if (threadIdx.x < MAXH) o[RED_Z + MAXH * HC + threadIdx.x] = db[threadIdx.x];
+}
+
+// finalize, one block per gate channel: parameter gradients and the apply-pass coefficients
+__global__ __launch_bounds__(64) void gate_bwd_finalize_kernel(const float* __restrict__ part, const double* __restrict__ mom_sum,
+                                                               const float* __restrict__ W1, const float* __restrict__ b1,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ W2,
+                                                               float* __restrict__ dW1, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dW2,
+                                                               float* __restrict__ db2, float* __restrict__ coef, double count) {
+  __shared__ double zs[XC + 2];
+  const int ch = blockIdx.x, t = threadIdx.x;
+  if (t < XC + 2) {
+    const bool want = t < XC + 1 || (ch % HC) == 0;
+    const size_t col = t < XC ? (size_t)ch * XC + t : (t == XC ? (size_t)RED_Z + ch : (size_t)RED_Z + MAXH * HC + ch / HC);
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+    if (want) {
+      for (int b = 0; b < RED_BLOCKS; b += 4) {
+        s0 += part[(size_t)b * RED_N + col];
+        s1 += part[(size_t)(b + 1) * RED_N + col];
+        s2 += part[(size_t)(b + 2) * RED_N + col];
+        s3 += part[(size_t)(b + 3) * RED_N + col];
+      }
+    }
+    zs[t] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  const float* w = W1 + (size_t)ch * XC;
+  const double Sr = zs[XC], w2 = W2[ch], gm = gamma[ch], rs = rstd[ch], mu = mean[ch], bb = b1[ch];
+  double wz = 0.;
+  for (int k = 0; k < XC; ++k) wz += (double)w[k] * zs[k];
+  const double Sb = w2 * Sr;                                  // sum_p da,  da = dr * w2
+  const double Sg = rs * (w2 * wz + (bb - mu) * Sb);          // sum_p da * that
+  const double c1 = gm * Sb / count, c2 = gm * Sg / count;
+  if (t == 0) {
+    dgamma[ch] += (float)Sg;
+    dbeta[ch] += (float)Sb;
+    dW2[ch] += (float)((double)scale[ch] * (wz + bb * Sr) + (double)shift[ch] * Sr);  // sum_p dpsi * relu(a)
+    if ((ch % HC) == 0) db2[ch / HC] += (float)zs[XC + 1];
+    const double K2 = -rs * rs * c2, K3 = -rs * c1 + mu * rs * rs * c2;
+    coef[4 * ch] = (float)(rs * w2 * gm);
+    coef[4 * ch + 1] = (float)K2;
+    coef[4 * ch + 2] = (float)(K2 * bb + K3);
+    coef[4 * ch + 3] = 0.f;
+  }
+  if (t < XC) {
+    double wm2 = 0.;
+    for (int j = 0; j < XC; ++j) wm2 += (double)w[j] * mom_sum[XC + j * XC + t];
+    const double tx = rs * (wm2 + (bb - mu) * mom_sum[t]);  // sum_p that_p x_p[t]
+    dW1[(size_t)ch * XC + t] += (float)(rs * (gm * w2 * zs[t] - c1 * mom_sum[t] - c2 * tx));
+  }
+}
+
+// Q[j][k] = sum_ch W1[ch,j] K2[ch] W1[ch,k],  r[k] = sum_ch (K2 b1 + K3)[ch] W1[ch,k]
+__global__ __launch_bounds__(1024) void gate_bwd_affine_kernel(const float* __restrict__ W1, const float* __restrict__ coef,
+                                                               float* __restrict__ Q, float* __restrict__ r, int nch) {
+  __shared__ float ws[MAXH * HC * XC];
+  __shared__ float k2[MAXH * HC], k3[MAXH * HC];
+  for (int e = threadIdx.x; e < nch * XC; e += 1024) ws[e] = W1[e];
+  for (int e = threadIdx.x; e < nch; e += 1024) k2[e] = coef[4 * e + 1], k3[e] = coef[4 * e + 2];
+  __syncthreads();
+  const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
+  double q = 0., rr = 0.;
+  for (int ch = 0; ch < nch; ++ch) {
+    q += (double)ws[ch * XC + j] * k2[ch] * ws[ch * XC + k];
+    if (j == 0) rr += (double)k3[ch] * ws[ch * XC + k];
+  }
+  Q[threadIdx.x] = (float)q;
+  if (j == 0) r[k] = (float)rr;
+}
+
+// apply pass: dF[p,k] = dXc[p,k] + x[p,:] Q[:,k] + r[k] + sum_ch dr[p,ch] K1[ch] W1[ch,k]
+__global__ __launch_bounds__(256, 2) void gate_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G,
+                                                                const float* __restrict__ dG, const float* __restrict__ dXc,
+                                                                const float* __restrict__ W1, const float* __restrict__ b1,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ coef, const float* __restrict__ Q,
+                                                                const float* __restrict__ r, bf16_t* __restrict__ dF,
+                                                                long long M, int NH) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int nch = NH * HC, nblk = (nch + 31) / 32;
+  __shared__ bf16x8 wK[NBLK * 2][64];  // K1*W1 operand, lane-indexed: rows = x channel l31, K slots = chained channels
+  __shared__ bf16x8 wAl[NBLK * 2][64];  // lo parts of W1s
+  bf16x8 wA[NBLK][2], qh[2], ql[2];
+  float biasf[NBLK];
+  uint32_t wbias[NBLK];
+  load_w1s(W1, b1, scale, shift, nch, lane, wave == 0, wA, wAl, biasf);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) ((uint4*)(dF + (size_t)p * XC))[v] = o[v];
+  for (int blk = 0; blk < NBLK; ++blk) wbias[blk] = half == 0 ? split_bf(biasf[blk]) : 0u;
+  for (int f = wave; f < NBLK * 2; f += 4) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (f >> 1) * 32 + acc_row(8 * (f & 1) + e, half);
+      v[e] = c < nch ? coef[4 * c] * W1[(size_t)c * XC + l31] : 0.f;
+    }
+    wK[f][lane] = frag8(v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {  // Q^T as (hi, lo) operands: row = k (l31), K slot = j
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = Q[(ks * 16 + half * 8 + e) * XC + l31];
+    frag8_split(f, qh[ks], ql[ks]);
+  }
+  const uint32_t rw = half == 0 ? split_bf(r[l31]) : 0u;
+  const bf16x8 ones = frag_lo(half == 0 ? 0x3f803f80u : 0u);
+
+  const long long ntile = (M + 31) / 32;
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
+    const long long p = t * 32 + l31;
+    const bool live = p < M;
+    Frag x0, x1;
+    load_x_frags(x, p, live, half, x0, x1);
+    float dpsi[MAXH];
+    if (live) {
+      float g[MAXH];
+      load_g16(G + (size_t)p * MAXH, g);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 d = ((const float4*)(dG + (size_t)p * MAXH))[v];
+        dpsi[4 * v] = d.x * g[4 * v] * (1.f - g[4 * v]);
+        dpsi[4 * v + 1] = d.y * g[4 * v + 1] * (1.f - g[4 * v + 1]);
+        dpsi[4 * v + 2] = d.z * g[4 * v + 2] * (1.f - g[4 * v + 2]);
+        dpsi[4 * v + 3] = d.w * g[4 * v + 3] * (1.f - g[4 * v + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h) dpsi[h] = 0.f;
+    }
+    f32x16 out = mfma(qh[0], x0.v, zero16());  // out^T[k, px]
+    out = mfma(qh[1], x1.v, out);
+    out = mfma(ql[0], x0.v, out);
+    out = mfma(ql[1], x1.v, out);
+    out = mfma(frag_lo(rw), ones, out);
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+      if (blk < nblk) {
+        f32x16 a = mfma(wA[blk][0], x0.v, zero16());  // a[ch, px]
+        a = mfma(wA[blk][1], x1.v, a);
+        a = mfma(wAl[2 * blk][lane], x0.v, a);
+        a = mfma(wAl[2 * blk + 1][lane], x1.v, a);
+        a = mfma(frag_lo(wbias[blk]), ones, a);
+        float dr[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dr[j] = a[j] > 0.f ? dpsi[2 * blk + (j >> 3)] : 0.f;
+        out = mfma(wK[2 * blk][lane], frag8(dr), out);
+        out = mfma(wK[2 * blk + 1][lane], frag8(dr + 8), out);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // rows (x channels) 8q + 4*half + {0..3} of this lane's pixel
+        const int k = 8 * q + 4 * half;
+        const float4 d = *(const float4*)(dXc + (size_t)p * XC + k);
+        *(uint2*)(dF + (size_t)p * XC + k) =
+            make_uint2(pack2bf(out[4 * q] + d.x, out[4 * q + 1] + d.y), pack2bf(out[4 * q + 2] + d.z, out[4 * q + 3] + d.w));
+      }
+    }
   }
 }
 
@@ -493,7 +774,7 @@ extern "C" {
 MVIT_API int mvit_heads_moments(const void* x, double* mom, long long M, int nslots, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || nslots <= 0) return MVIT_EINVAL;
-  hipLaunchKernelGGL(moments_kernel, dim3(nblk(M, 64 * 8, 1024)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mom, M,
+  hipLaunchKernelGGL(moments_kernel, dim3(nblk(M, 32 * 4 * 4, 512)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mom, M,
                      nslots);
   return MVIT_LAUNCH_CHECK();
 }
@@ -504,7 +785,7 @@ MVIT_API int mvit_heads_bn_from_moments(const double* mom, const float* W1, cons
                                         double count, float eps, float momentum, int training, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (NH <= 0 || NH > MAXH || (training && (!mom || nslots <= 0 || count <= 0))) return MVIT_EINVAL;
-  hipLaunchKernelGGL(bn_from_moments_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mom, W1, b1, gamma, beta,
+  hipLaunchKernelGGL(bn_from_moments_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mom, W1, b1, gamma, beta,
                      running_mean, running_var, scale, shift, mean_out, rstd_out, mom_sum, NH * HC, nslots, count, eps,
                      momentum, training);
   return MVIT_LAUNCH_CHECK();
@@ -514,7 +795,7 @@ MVIT_API int mvit_heads_gate_fwd(const void* x, const float* W1, const float* b1
                                  const float* W2, const float* b2, void* G, long long M, int NH, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
-  hipLaunchKernelGGL(gate_fwd_kernel, dim3(nblk(M, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, W1, b1,
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(nblk(M, 32 * 4 * 4, 512)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, W1, b1,
                      scale, shift, W2, b2, (bf16_t*)G, M, NH);
   return MVIT_LAUNCH_CHECK();
 }
@@ -537,20 +818,25 @@ MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x,
   return MVIT_LAUNCH_CHECK();
 }
 
+MVIT_API long long mvit_heads_gate_bwd_scratch_bytes(void) { return (long long)(SCR_FLOATS * sizeof(float)); }
+
 MVIT_API int mvit_heads_gate_bwd(const void* x, const void* G, const float* dG, const float* dXc, const float* W1,
                                  const float* b1, const float* scale, const float* shift, const float* mean,
-                                 const float* rstd, const float* gamma, const float* W2, const double* mom_sum, double* red,
-                                 float* coef, float* dW1, float* dgamma, float* dbeta, float* dW2, float* db2, void* dF,
-                                 long long M, int NH, int nslots, double count, mvit_stream_t stream) {
+                                 const float* rstd, const float* gamma, const float* W2, const double* mom_sum,
+                                 void* scratch, long long scratch_bytes, float* dW1, float* dgamma, float* dbeta, float* dW2,
+                                 float* db2, void* dF, long long M, int NH, double count, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || NH <= 0 || NH > MAXH || nslots <= 0) return MVIT_EINVAL;
+  if (M <= 0 || NH <= 0 || NH > MAXH || !scratch || scratch_bytes < (long long)(SCR_FLOATS * sizeof(float))) return MVIT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gate_bwd_reduce_kernel, dim3(nblk(M, GR_ROWS * 16, 512)), dim3(256), 0, s, (const bf16_t*)x,
-                     (const bf16_t*)G, dG, W1, b1, scale, shift, mean, rstd, gamma, W2, red, M, NH, nslots);
-  hipLaunchKernelGGL(gate_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, red, mom_sum, W1, b1, mean, rstd, gamma, dW1, dgamma,
-                     dbeta, dW2, db2, coef, NH, nslots, count);
-  hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(nblk(M, 256, 4096)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)G, dG,
-                     dXc, W1, b1, scale, shift, mean, rstd, gamma, W2, coef, (bf16_t*)dF, M, NH);
+  float* part = (float*)scratch;
+  float *coef = part + SCR_COEF, *Q = part + SCR_Q, *r = part + SCR_R;
+  hipLaunchKernelGGL(gate_bwd_reduce_kernel, dim3(RED_BLOCKS), dim3(512), 0, s, (const bf16_t*)x, (const bf16_t*)G, dG, W1, b1,
+                     scale, shift, part, M, NH);
+  hipLaunchKernelGGL(gate_bwd_finalize_kernel, dim3(NH * HC), dim3(64), 0, s, part, mom_sum, W1, b1, scale, shift, mean, rstd,
+                     gamma, W2, dW1, dgamma, dbeta, dW2, db2, coef, count);
+  hipLaunchKernelGGL(gate_bwd_affine_kernel, dim3(1), dim3(1024), 0, s, W1, coef, Q, r, NH * HC);
+  hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(nblk(M, 32 * 4 * 4, 512)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)G,
+                     dG, dXc, W1, b1, scale, shift, coef, Q, r, (bf16_t*)dF, M, NH);
   return MVIT_LAUNCH_CHECK();
 }
 

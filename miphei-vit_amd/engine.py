@@ -361,7 +361,7 @@ class HipEngine:
                     rstd=e(ch, dt=torch.float32)) for ch in chans]
         w.hbn = NS(scale=e(nch, dt=torch.float32), shift=e(nch, dt=torch.float32), mean=e(nch, dt=torch.float32),
                    rstd=e(nch, dt=torch.float32))
-        # f64 arena: forward stats | heads moments | mom_sum | (backward) stats | heads red | loss | sqnorm
+        # f64 arena: forward stats | heads moments | mom_sum | (backward) stats | loss | sqnorm
         sizes = [NSLOTS * 2 * ch for ch in chans] + [NSLOTS * (32 + 1024), 32 + 1024]
         w.arena_f = z(sum(sizes), dt=torch.float64)
         offs = [0]
@@ -371,13 +371,12 @@ class HipEngine:
         w.mom = w.arena_f[offs[7]:offs[8]]
         w.mom_sum = w.arena_f[offs[8]:offs[9]]
         if train:
-            sizes_b = [NSLOTS * 2 * ch for ch in chans] + [NSLOTS * nch * 36, 2]
+            sizes_b = [NSLOTS * 2 * ch for ch in chans] + [0, 2]
             w.arena_b = z(sum(sizes_b), dt=torch.float64)
             ob = [0]
             for s_ in sizes_b:
                 ob.append(ob[-1] + s_)
             w.stats_b = [w.arena_b[ob[i]:ob[i + 1]] for i in range(7)]
-            w.hred = w.arena_b[ob[7]:ob[8]]
             w.loss_acc = w.arena_b[ob[8]:ob[8] + 1]
             w.sqn = w.arena_b[ob[8] + 1:ob[8] + 2]
             # gradients / scratch
@@ -386,7 +385,7 @@ class HipEngine:
             w.dG = e(B * S * S, 16, dt=torch.float32)
             w.dXc = e(B * S * S, HEAD_C, dt=torch.float32)
             w.dF3 = e(B * S * S, HEAD_C)
-            w.coef = e(nch, 2, dt=torch.float32)
+            w.hscr = e(ops.heads_gate_bwd_scratch_bytes() // 4, dt=torch.float32)
             w.db3_slots = z(64, 32, dt=torch.float32)
             w.dpre_c = [e(B * s1 * s1, 48), e(B * s2 * s2, 96), e(B * s3 * s3, 192)]
             w.dpre_f = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64), e(B * S * S, 32)]
@@ -618,8 +617,7 @@ class HipEngine:
         ops.gemm(w.ET, xT, w.dW3, M=c.NH * 9, N=HEAD_C, K=Mp, lda=Mp, ldb=Mp, ldc=HEAD_C, flags=OUT_F32 | ATOMIC, ksplit=ks)
         fl.dW3.add_(w.dW3.view(c.NH, 9, HEAD_C).transpose(1, 2))
         ops.heads_gate_bwd(w.F3, w.G, w.dG, w.dXc, pk.W1, pk.b1, w.hbn.scale, w.hbn.shift, w.hbn.mean, w.hbn.rstd, pk.bnw,
-                           pk.W2, w.mom_sum, w.hred, w.coef, fl.dW1, fl.dbnw, fl.dbnb, fl.dW2, fl.db2, w.dF3, Mp, c.NH,
-                           NSLOTS)
+                           pk.W2, w.mom_sum, w.hscr, fl.dW1, fl.dbnw, fl.dbnb, fl.dW2, fl.db2, w.dF3, Mp, c.NH)
         # ---- fusion blocks (reverse)
         res = [s3, s2, s1, S]
         dy_post, ld_post = w.dF3, HEAD_C

@@ -228,11 +228,15 @@ def heads_conv_bwd(dY, Y, x, G, W3, ET, dG, dXc, db3, B, H, W, NH):
     _call("mvit_heads_conv_bwd", _p(dY), _p(Y), _p(x), _p(G), _p(W3), _p(ET), _p(dG), _p(dXc), _p(db3), B, H, W, NH)
 
 
-def heads_gate_bwd(x, G, dG, dXc, W1, b1, scale, shift, mean, rstd, gamma, W2, mom_sum, red, coef, dW1, dgamma, dbeta, dW2,
-                   db2, dF, M, NH, nslots):
+def heads_gate_bwd_scratch_bytes():
+    return int(L.lib().mvit_heads_gate_bwd_scratch_bytes())
+
+
+def heads_gate_bwd(x, G, dG, dXc, W1, b1, scale, shift, mean, rstd, gamma, W2, mom_sum, scratch, dW1, dgamma, dbeta, dW2,
+                   db2, dF, M, NH):
     _call("mvit_heads_gate_bwd", _p(x), _p(G), _p(dG), _p(dXc), _p(W1), _p(b1), _p(scale), _p(shift), _p(mean), _p(rstd),
-          _p(gamma), _p(W2), _p(mom_sum), _p(red), _p(coef), _p(dW1), _p(dgamma), _p(dbeta), _p(dW2), _p(db2), _p(dF), M,
-          NH, nslots, float(M))
+          _p(gamma), _p(W2), _p(mom_sum), _p(scratch), scratch.numel() * scratch.element_size(), _p(dW1), _p(dgamma),
+          _p(dbeta), _p(dW2), _p(db2), _p(dF), M, NH, float(M))
 
 
 def wmse_fwd_bwd(pred, target, w, loss_acc, dY, lambda_factor):
