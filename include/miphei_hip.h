@@ -163,9 +163,12 @@ MVIT_API int mvit_heads_gate_fwd(const void* x, const float* W1, const float* b1
                                  mvit_stream_t stream);
 MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, const float* b3, float* out /*NCHW f32*/,
                                  int B, int H, int W, int NH, mvit_stream_t stream);
+/* scratch: bf16 dz map [M,16] + per-block partial sums of dW3 */
+MVIT_API long long mvit_heads_conv_bwd_scratch_bytes(long long M);
 MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x, const void* G, const float* W3,
-                                 void* ET /*bf16 [NH*9, M]*/, float* dG /*[M,16]*/, float* dXc /*[M,32]*/,
-                                 float* db3 /*[64 slots][32] partial sums, zeroed; sum over slots*/, int B,
+                                 void* scratch, long long scratch_bytes, float* dG /*[M,16]*/, float* dXc /*[M,32]*/,
+                                 float* dW3 /*[NH*9][32], overwritten*/,
+                                 float* db3 /*[64 slots][32] partial sums, zeroed, summed by the caller*/, int B,
                                  int H, int W, int NH, mvit_stream_t stream);
 /* scratch for mvit_heads_gate_bwd: per-block partial sums of the reduction pass + the apply-pass coefficients */
 MVIT_API long long mvit_heads_gate_bwd_scratch_bytes(void);

@@ -63,7 +63,8 @@ SIGNATURES = {
     "mvit_heads_bn_from_moments": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cf, cf, ci, vp],
     "mvit_heads_gate_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp],
     "mvit_heads_conv_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
-    "mvit_heads_conv_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mvit_heads_conv_bwd_scratch_bytes": [ll],
+    "mvit_heads_conv_bwd": [vp, vp, vp, vp, vp, vp, ll, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_heads_gate_bwd_scratch_bytes": [],
     "mvit_heads_gate_bwd": [vp] * 14 + [ll] + [vp] * 6 + [ll, ci, cd, vp],
     "mvit_wmse_fwd_bwd": [vp, vp, vp, vp, vp, ci, ci, ll, cf, vp],

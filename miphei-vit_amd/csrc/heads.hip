@@ -356,90 +356,213 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
-// ------------------------------------------------------------------ backward of the gated conv (thread per pixel q)
-// dz[p,h] = dY*(1-y^2);  ET[(h,d)][q] = g[q,h]*dz[q-d+1,h];  dG[q,h] = sum_c x_c v_hc;  dXc[q,c] = sum_h g_h v_hc
-// with v_hc = sum_d dz[q-d+1,h] * W3[h][d][c].   db3[h] += sum_p dz[p,h].
-__global__ __launch_bounds__(256) void conv_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
-                                                       const bf16_t* __restrict__ x, const bf16_t* __restrict__ G,
-                                                       const float* __restrict__ W3, bf16_t* __restrict__ ET,
-                                                       float* __restrict__ dG, float* __restrict__ dXc,
-                                                       float* __restrict__ db3, int B, int H, int W, int NH) {
-  __shared__ __attribute__((aligned(16))) float w3s[MAXH * 9 * XC];
-  for (int e = threadIdx.x; e < NH * 9 * XC; e += 256) w3s[e] = W3[e];
-  __syncthreads();
-  const long long M = (long long)B * H * W;
-  const size_t plane = (size_t)H * W;
+// ------------------------------------------------------------------ backward of the gated conv, on MFMA
+// dz[p,h] = dY*(1-y^2) (pre-pass, bf16 NHWC).  Per pixel q and 3x3 offset d (p = q - d + 1):
+//   E[q,(d,h)]  = g[q,h] * dz[p,h]
+//   dXc[q,c]    = sum_(d,h) E[q,(d,h)] W3[h,d,c]                 (K = 144 chain of nine k-steps, one per offset)
+//   T[q,(d,h)]  = sum_c x[q,c] W3[h,d,c];  dG[q,h] = sum_d dz[p,h] T[q,(d,h)]
+//   dW3[h,d,c]  = sum_q E[q,(d,h)] x[q,c]                        (E and x tiles transposed through LDS)
+// db3[h] = sum_p dz[p,h] comes out of the pre-pass.
+constexpr int CB_BLOCKS = 512;              // persistent grid of the main pass = rows of the dW3 partial buffer
+constexpr int CB_COLS = 160;                // 9*16 (d,h) columns padded to five 32-column blocks
+constexpr int CB_PART = CB_COLS * XC;       // floats per partial row
+constexpr int ET_STRIDE = 336;              // bytes per pixel row of the E tile (160 bf16 + pad: conflict-free 16-byte stores)
+
+__global__ __launch_bounds__(256) void conv_bwd_dz_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                          bf16_t* __restrict__ dzb, float* __restrict__ db3, int B,
+                                                          long long HW, int NH) {
+  const long long M = (long long)B * HW;
   float db_acc[MAXH];
 #pragma unroll
   for (int h = 0; h < MAXH; ++h) db_acc[h] = 0.f;
-  for (long long q0 = (long long)blockIdx.x * 256; q0 < M; q0 += (long long)gridDim.x * 256) {
-    const long long q = q0 + threadIdx.x;
-    const bool live = q < M;
-    const long long qq = live ? q : 0;
-    const int qx = (int)(qq % W);
-    const long long t = qq / W;
-    const int qy = (int)(t % H), b = (int)(t / H);
-    float xv[XC], g[MAXH], dx[XC];
-    load_x32(x + (size_t)qq * XC, xv);
-    load_g16(G + (size_t)qq * MAXH, g);
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < M; p += (long long)gridDim.x * 256) {
+    const long long b = p / HW, pix = p - b * HW;
+    float dz[MAXH];
 #pragma unroll
-    for (int c = 0; c < XC; ++c) dx[c] = 0.f;
-    for (int h = 0; h < NH; ++h) {
-      float gh = 0.f;
-#pragma unroll
-      for (int hh = 0; hh < MAXH; ++hh)
-        if (hh == h) gh = g[hh];
-      float v[XC];
-#pragma unroll
-      for (int c = 0; c < XC; ++c) v[c] = 0.f;
-      float dzc = 0.f;
-      const float* dyp = dY + ((size_t)b * NH + h) * plane;
-      const float* yp = Y + ((size_t)b * NH + h) * plane;
-#pragma unroll 1
-      for (int d = 0; d < 9; ++d) {
-        const int py = qy - (d / 3) + 1, px = qx - (d % 3) + 1;
-        float dz = 0.f;
-        if (live && py >= 0 && py < H && px >= 0 && px < W) {
-          const size_t pi = (size_t)py * W + px;
-          const float yy = yp[pi];
-          dz = dyp[pi] * (1.f - yy * yy);
-        }
-        if (d == 4) dzc = dz;
-        if (live) ET[((size_t)h * 9 + d) * M + q] = f2bf(gh * dz);
-        const float4* w = (const float4*)(w3s + (h * 9 + d) * XC);
-#pragma unroll
-        for (int k = 0; k < XC / 4; ++k) {
-          const float4 ww = w[k];
-          v[4 * k] += dz * ww.x;
-          v[4 * k + 1] += dz * ww.y;
-          v[4 * k + 2] += dz * ww.z;
-          v[4 * k + 3] += dz * ww.w;
-        }
+    for (int h = 0; h < MAXH; ++h) {
+      dz[h] = 0.f;
+      if (h < NH) {
+        const size_t i = ((size_t)b * NH + h) * HW + pix;
+        const float yy = Y[i];
+        dz[h] = dY[i] * (1.f - yy * yy);
+        db_acc[h] += dz[h];
       }
-      float dg = 0.f;
-#pragma unroll
-      for (int c = 0; c < XC; ++c) {
-        dg += xv[c] * v[c];
-        dx[c] += gh * v[c];
-      }
-      if (live) dG[(size_t)q * MAXH + h] = dg;
-#pragma unroll
-      for (int hh = 0; hh < MAXH; ++hh)
-        if (hh == h) db_acc[hh] += dzc;
     }
-    if (live) {
+    uint4 o[2];
+    uint32_t* ou = (uint32_t*)o;
 #pragma unroll
-      for (int k = 0; k < XC / 4; ++k)
-        ((float4*)(dXc + (size_t)q * XC))[k] = make_float4(dx[4 * k], dx[4 * k + 1], dx[4 * k + 2], dx[4 * k + 3]);
-    }
+    for (int j = 0; j < 8; ++j) ou[j] = pack2bf(dz[2 * j], dz[2 * j + 1]);
+    ((uint4*)(dzb + (size_t)p * MAXH))[0] = o[0];
+    ((uint4*)(dzb + (size_t)p * MAXH))[1] = o[1];
   }
-  // db3[h] += sum_p dz[p,h]: one atomic per wave and head, spread over DB3_SLOTS cache lines (summed by the caller)
   const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % DB3_SLOTS;
 #pragma unroll
   for (int h = 0; h < MAXH; ++h) {
     const float s = wave_sum(db_acc[h]);
     if ((threadIdx.x & 63) == 0 && h < NH) atomicAdd(db3 + slot * 32 + h, s);
   }
+}
+
+// transposed K operand from a tile with `stride`-byte rows: slot e of k-step ks <-> tile row acc_row(8*ks+e, half), col l31
+__device__ __forceinline__ bf16x8 tile_T_frag_s(const char* tile, int stride, int ks, int lane) {
+  const int i = lane & 15, half = lane >> 5;
+  const char* p = tile + (ks * 16 + 4 * half + (i >> 2)) * stride + (16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
+  Frag r;
+  r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
+  r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 8 * stride));
+  return r.v;
+}
+
+__global__ __launch_bounds__(256, 1) void conv_bwd_kernel(const bf16_t* __restrict__ dzb, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ G, const float* __restrict__ W3,
+                                                          float* __restrict__ dG, float* __restrict__ dXc,
+                                                          float* __restrict__ part, int B, int H, int W, int NH) {
+  // lane-indexed operand tables: W3c[d] (rows = x channel, K = head) for dXc, W3r[blk][ks] (rows = (d,h), K = x channel) for T
+  __shared__ bf16x8 W3c[9][64];
+  __shared__ bf16x8 W3r[10][64];
+  __shared__ bf16x8 W3rl[10][64];  // lo parts: T feeds the gate gradient, whose per-head sums cancel heavily
+  __shared__ __attribute__((aligned(16))) char tiles[4][32 * ET_STRIDE + 2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  for (int f = wave; f < 19; f += 4) {
+    float v[8];
+    if (f < 9) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int h = half * 8 + e;
+        v[e] = h < NH ? W3[((size_t)h * 9 + f) * XC + l31] : 0.f;
+      }
+      W3c[f][lane] = frag8(v);
+    } else {
+      // row rho = l31 of block blk holds (d, h) = (2*blk + (j >> 3), 8*hr + (j & 7)) with rho = acc_row(j, hr): the lane that
+      // receives accumulator register j then owns heads 8*half .. 8*half+7, the ones its dz / gate loads cover
+      const int blk = (f - 9) >> 1, ks = (f - 9) & 1;
+      const int j = (l31 & 3) + 4 * (l31 >> 3), hr = (l31 >> 2) & 1;
+      const int d = 2 * blk + (j >> 3), h = 8 * hr + (j & 7);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (d < 9 && h < NH) ? W3[((size_t)h * 9 + d) * XC + ks * 16 + half * 8 + e] : 0.f;
+      frag8_split(v, W3r[f - 9][lane], W3rl[f - 9][lane]);
+    }
+  }
+  __syncthreads();
+  char* et = tiles[wave];
+  char* xt = et + 32 * ET_STRIDE;
+  // columns 144..159 of the E tile are never written: zero them once so the padded dW3 columns stay finite
+  *(uint4*)(et + l31 * ET_STRIDE + 288 + half * 16) = make_uint4(0, 0, 0, 0);
+  f32x16 dw[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) dw[c] = zero16();
+
+  const int M = B * H * W, ntile = (M + 31) / 32;  // the launcher bounds M to 31 bits: 32-bit pixel arithmetic
+  for (int t = blockIdx.x * 4 + wave; t < ntile; t += gridDim.x * 4) {
+    const int p = t * 32 + l31;
+    const bool live = p < M;
+    const int pp = live ? p : 0;
+    const int qx = pp % W;
+    const int qy = (pp / W) % H;
+    Frag x0, x1;
+    load_x_frags(x, p, live, half, x0, x1);
+    float g[8];
+    {
+      uint4 gq = make_uint4(0, 0, 0, 0);
+      if (live) gq = *(const uint4*)(G + (size_t)p * MAXH + half * 8);
+      const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = __uint_as_float((e & 1) ? (gu[e >> 1] & 0xffff0000u) : (gu[e >> 1] << 16));
+    }
+    uint4 dzq[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+      const int py = qy - d / 3 + 1, px = qx - d % 3 + 1;
+      dzq[d] = make_uint4(0, 0, 0, 0);
+      if (live && py >= 0 && py < H && px >= 0 && px < W)
+        dzq[d] = *(const uint4*)(dzb + (size_t)(p + (1 - d / 3) * W + (1 - d % 3)) * MAXH + half * 8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    *(uint4*)(xt + l31 * 64 + half * 16) = x0.q;
+    *(uint4*)(xt + l31 * 64 + 32 + half * 16) = x1.q;
+    int tl = lane;  // opaque per iteration: keeps the operand-table reads inside the loop instead of 76 hoisted registers
+    asm volatile("" : "+v"(tl));
+    f32x16 dxc = zero16();
+    float dg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg[e] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 5; ++blk) {
+      f32x16 T = mfma(W3r[2 * blk][tl], x0.v, zero16());  // T^T[(d,h), q] for offsets d = 2*blk, 2*blk+1
+      T = mfma(W3r[2 * blk + 1][tl], x1.v, T);
+      T = mfma(W3rl[2 * blk][tl], x0.v, T);
+      T = mfma(W3rl[2 * blk + 1][tl], x1.v, T);
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+        const int d = 2 * blk + dd;
+        if (d < 9) {
+          const uint32_t du[4] = {dzq[d].x, dzq[d].y, dzq[d].z, dzq[d].w};
+          float ev[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dz = __uint_as_float((e & 1) ? (du[e >> 1] & 0xffff0000u) : (du[e >> 1] << 16));
+            dg[e] += dz * T[8 * dd + e];
+            ev[e] = g[e] * dz;
+          }
+          Frag E;
+          E.v = frag8(ev);
+          *(uint4*)(et + l31 * ET_STRIDE + d * 32 + half * 16) = E.q;
+          dxc = mfma(W3c[d][tl], E.v, dxc);  // dXc^T[c, q]
+        }
+      }
+    }
+    if (live) {
+      *(float4*)(dG + (size_t)p * MAXH + half * 8) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+      *(float4*)(dG + (size_t)p * MAXH + half * 8 + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(float4*)(dXc + (size_t)p * XC + 8 * q + 4 * half) = make_float4(dxc[4 * q], dxc[4 * q + 1], dxc[4 * q + 2], dxc[4 * q + 3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bf16x8 xT0 = tile_T_frag(xt, 0, lane), xT1 = tile_T_frag(xt, 1, lane);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {  // dW3^T[ch, (d,h)]: rows = x channel, cols = 32 (d,h) columns of block c
+      dw[c] = mfma(xT0, tile_T_frag_s(et + c * 64, ET_STRIDE, 0, lane), dw[c]);
+      dw[c] = mfma(xT1, tile_T_frag_s(et + c * 64, ET_STRIDE, 1, lane), dw[c]);
+    }
+  }
+  // ---- block reduction, one partial row [160 (d,h) columns][32 channels] per block
+  float* zb = (float*)&tiles[0][0];  // [5][16][64]
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float* q = zb + (c * 16 + j) * 64 + lane;
+          *q = (w == 0 ? 0.f : *q) + dw[c][j];
+        }
+    }
+    __syncthreads();
+  }
+  float* o = part + (size_t)blockIdx.x * CB_PART;
+  for (int e = threadIdx.x; e < 5 * 16 * 64; e += 256) {
+    const int ln = e & 63, j = (e >> 6) & 15, c = e >> 10;
+    o[(c * 32 + (ln & 31)) * XC + acc_row(j, ln >> 5)] = zb[e];
+  }
+}
+
+// dW3[(h*9+d)*32 + c] = sum over the partial rows of column d*16+h
+__global__ __launch_bounds__(256) void conv_bwd_dw3_kernel(const float* __restrict__ part, float* __restrict__ dW3, int NH, int nrows) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= NH * 9 * XC) return;
+  const int c = o % XC, hd = o / XC, h = hd / 9, d = hd % 9;
+  const size_t col = (size_t)(d * 16 + h) * XC + c;
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+  for (int b = 0; b < nrows; b += 4) {
+    s0 += part[(size_t)b * CB_PART + col];
+    s1 += part[(size_t)(b + 1) * CB_PART + col];
+    s2 += part[(size_t)(b + 2) * CB_PART + col];
+    s3 += part[(size_t)(b + 3) * CB_PART + col];
+  }
+  dW3[o] = (float)((s0 + s1) + (s2 + s3));
 }
 
 // ------------------------------------------------------------------ gate backward
@@ -809,12 +932,24 @@ MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, 
   return MVIT_LAUNCH_CHECK();
 }
 
-MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x, const void* G, const float* W3, void* ET,
-                                 float* dG, float* dXc, float* db3, int B, int H, int W, int NH, mvit_stream_t stream) {
+MVIT_API long long mvit_heads_conv_bwd_scratch_bytes(long long M) {
+  return (long long)(((size_t)M * MAXH * sizeof(bf16_t) + 255) / 256 * 256 + (size_t)CB_BLOCKS * CB_PART * sizeof(float));
+}
+
+MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x, const void* G, const float* W3, void* scratch,
+                                 long long scratch_bytes, float* dG, float* dXc, float* dW3, float* db3, int B, int H, int W,
+                                 int NH, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (B <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
-  hipLaunchKernelGGL(conv_bwd_kernel, dim3(nblk((long long)B * H * W, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dY, Y,
-                     (const bf16_t*)x, (const bf16_t*)G, W3, (bf16_t*)ET, dG, dXc, db3, B, H, W, NH);
+  if (B <= 0 || H <= 0 || W <= 0 || NH <= 0 || NH > MAXH || !scratch) return MVIT_EINVAL;
+  const long long M = (long long)B * H * W;
+  if (M >= (1ll << 31) - 64 || scratch_bytes < mvit_heads_conv_bwd_scratch_bytes(M)) return MVIT_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t* dzb = (bf16_t*)scratch;
+  float* part = (float*)((char*)scratch + ((size_t)M * MAXH * sizeof(bf16_t) + 255) / 256 * 256);
+  hipLaunchKernelGGL(conv_bwd_dz_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, s, dY, Y, dzb, db3, B, (long long)H * W, NH);
+  hipLaunchKernelGGL(conv_bwd_kernel, dim3(CB_BLOCKS), dim3(256), 0, s, (const bf16_t*)dzb, (const bf16_t*)x, (const bf16_t*)G, W3,
+                     dG, dXc, part, B, H, W, NH);
+  hipLaunchKernelGGL(conv_bwd_dw3_kernel, dim3((NH * 9 * XC + 255) / 256), dim3(256), 0, s, (const float*)part, dW3, NH, CB_BLOCKS);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -381,7 +381,7 @@ class HipEngine:
             w.sqn = w.arena_b[ob[8] + 1:ob[8] + 2]
             # gradients / scratch
             w.dY = e(B, c.NH, S, S, dt=torch.float32)
-            w.ET = e(c.NH * 9, B * S * S)
+            w.cscr = e(ops.heads_conv_bwd_scratch_bytes(B * S * S) // 4, dt=torch.float32)
             w.dG = e(B * S * S, 16, dt=torch.float32)
             w.dXc = e(B * S * S, HEAD_C, dt=torch.float32)
             w.dF3 = e(B * S * S, HEAD_C)
@@ -395,7 +395,6 @@ class HipEngine:
             w.dfeat = e(B, G, G, D)
             pix = [B * s1 * s1, B * s2 * s2, B * s3 * s3, B * s3 * s3, B * s2 * s2, B * s1 * s1, B * S * S]
             cinp = [8, 48, 96, _pad8(192 + D), _pad8(96 + 256), _pad8(48 + 128), _pad8(3 + 64)]
-            w.dyT = e(HEAD_C * B * S * S)
             wsz = [9 * cp * ch for cp, ch in zip(cinp, chans)] + [c.NH * 9 * HEAD_C]
             w.wscr = z(sum(wsz), dt=torch.float32)
             ow = [0]
@@ -609,12 +608,8 @@ class HipEngine:
         dY = dY.to(torch.float32).contiguous()
         # ---- heads
         w.db3_slots.zero_()
-        ops.heads_conv_bwd(dY, w.out, w.F3, w.G, pk.W3k, w.ET, w.dG, w.dXc, w.db3_slots, B, S, S, c.NH)
+        ops.heads_conv_bwd(dY, w.out, w.F3, w.G, pk.W3k, w.cscr, w.dG, w.dXc, w.dW3, w.db3_slots, B, S, S, c.NH)
         fl.db3.add_(w.db3_slots.sum(0)[:c.NH])
-        xT = w.dyT[:HEAD_C * Mp].view(HEAD_C, Mp)
-        ops.transpose_bf16(w.F3, xT, Mp, HEAD_C, HEAD_C, Mp)
-        ks = max(1, min(512, Mp // 512))
-        ops.gemm(w.ET, xT, w.dW3, M=c.NH * 9, N=HEAD_C, K=Mp, lda=Mp, ldb=Mp, ldc=HEAD_C, flags=OUT_F32 | ATOMIC, ksplit=ks)
         fl.dW3.add_(w.dW3.view(c.NH, 9, HEAD_C).transpose(1, 2))
         ops.heads_gate_bwd(w.F3, w.G, w.dG, w.dXc, pk.W1, pk.b1, w.hbn.scale, w.hbn.shift, w.hbn.mean, w.hbn.rstd, pk.bnw,
                            pk.W2, w.mom_sum, w.hscr, fl.dW1, fl.dbnw, fl.dbnb, fl.dW2, fl.db2, w.dF3, Mp, c.NH)

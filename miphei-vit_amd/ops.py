@@ -224,8 +224,13 @@ def heads_conv_fwd(x, G, W3, b3, out, B, H, W, NH):
     _call("mvit_heads_conv_fwd", _p(x), _p(G), _p(W3), _p(b3), _p(out), B, H, W, NH)
 
 
-def heads_conv_bwd(dY, Y, x, G, W3, ET, dG, dXc, db3, B, H, W, NH):
-    _call("mvit_heads_conv_bwd", _p(dY), _p(Y), _p(x), _p(G), _p(W3), _p(ET), _p(dG), _p(dXc), _p(db3), B, H, W, NH)
+def heads_conv_bwd_scratch_bytes(M):
+    return int(L.lib().mvit_heads_conv_bwd_scratch_bytes(M))
+
+
+def heads_conv_bwd(dY, Y, x, G, W3, scratch, dG, dXc, dW3, db3, B, H, W, NH):
+    _call("mvit_heads_conv_bwd", _p(dY), _p(Y), _p(x), _p(G), _p(W3), _p(scratch), scratch.numel() * scratch.element_size(),
+          _p(dG), _p(dXc), _p(dW3), _p(db3), B, H, W, NH)
 
 
 def heads_gate_bwd_scratch_bytes():

@@ -85,3 +85,52 @@ def test_gate_forward_backward(NH, M):
     assert rel(dW2, dW2_ref) < tol
     assert rel(db2, db2_ref) < tol
     assert float(db1_ref.abs().max()) < 1e-2 * float(dbet_ref.abs().max() + 1e-6)  # conv bias before train-mode BN: zero gradient
+
+
+@pytest.mark.parametrize("NH,B,H,W", [(16, 2, 40, 40), (3, 1, 24, 31), (5, 3, 9, 7)])
+def test_gated_conv_backward(NH, B, H, W):
+    """backward of y = tanh(conv3x3(x * g_h) + b3) per head (SegmentationHead, src/generators/unet.py:430-438) against
+    torch autograd in fp32: dG (gate gradient), dXc (feature gradient through the conv), dW3, db3."""
+    import torch.nn.functional as F
+    import miphei_vit_amd.ops as ops
+    torch.manual_seed(NH + B * 7 + H)
+    dev = "cuda"
+    M = B * H * W
+    x = torch.randn(M, XC, device=dev).bfloat16()
+    G = torch.zeros(M, 16, device=dev)
+    G[:, :NH] = torch.rand(M, NH, device=dev)
+    G = G.bfloat16()
+    W3 = torch.randn(NH, 9, XC, device=dev) * 0.1          # kernel layout [head][ky*3+kx][channel]
+    b3 = torch.randn(NH, device=dev) * 0.1
+    dY = torch.randn(B, NH, H, W, device=dev)
+
+    xr = x.float().view(B, H, W, XC).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gr = G.float().view(B, H, W, 16).permute(0, 3, 1, 2)[:, :NH].clone().requires_grad_(True)
+    w = W3.view(NH, 3, 3, XC).permute(0, 3, 1, 2).clone().requires_grad_(True)     # [head, c, ky, kx]
+    bb = b3.clone().requires_grad_(True)
+    ys = [torch.tanh(F.conv2d(xr * gr[:, h:h + 1], w[h:h + 1], bb[h:h + 1], padding=1)) for h in range(NH)]
+    Y = torch.cat(ys, 1)
+    (Y * dY).sum().backward()
+
+    out = torch.empty(B, NH, H, W, device=dev)
+    ops.heads_conv_fwd(x, G, W3, b3, out, B, H, W, NH)
+    assert float((out - Y.detach()).abs().max()) < 1e-3
+
+    scratch = torch.empty(ops.heads_conv_bwd_scratch_bytes(M) // 4 + 1, device=dev)
+    dG = torch.empty(M, 16, device=dev)
+    dXc = torch.empty(M, XC, device=dev)
+    dW3 = torch.empty(NH * 9, XC, device=dev)
+    db3 = torch.zeros(64, 32, device=dev)
+    ops.heads_conv_bwd(dY, out, x, G, W3, scratch, dG, dXc, dW3, db3, B, H, W, NH)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+
+    dG_ref = gr.grad.permute(0, 2, 3, 1).reshape(M, NH)
+    dX_ref = xr.grad.permute(0, 2, 3, 1).reshape(M, XC)
+    dW_ref = w.grad.permute(0, 2, 3, 1).reshape(NH * 9, XC)
+    assert rel(dG[:, :NH], dG_ref) < 1e-2       # bf16 dz / W3 operands, fp32 accumulation
+    assert rel(dXc, dX_ref) < 1e-2
+    assert rel(dW3, dW_ref) < 1e-2
+    assert rel(db3.sum(0)[:NH], bb.grad) < 1e-3
