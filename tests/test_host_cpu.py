@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         g.build()
     hdr = open(os.path.join(ROOT, "include", "miphei_hip.h")).read()
-    declared = set(re.findall(r"MVIT_API\s+int\s+(mvit_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"MVIT_API\s+(?:int|long long)\s+(mvit_\w+)\s*\(", hdr))
     assert len(declared) >= 30
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     handle = ctypes.CDLL(_lib.LIB_PATH)
