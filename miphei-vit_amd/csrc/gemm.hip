@@ -49,9 +49,13 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   static const int huge_min_tiles = [] { const char* e = getenv("MVIT_GEMM_HUGE_MIN_TILES"); return e ? atoi(e) : 600; }();
   const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const bool huge = big && dense && (a.N % 256 == 0) && tiles256 >= huge_min_tiles && a.ksplit <= 1;
+  // one-wave-per-SIMD variants (4 waves, 128-row sub-tiles, register-double-buffered fragments): MVIT_GEMM_W4 bit 0
+  // forces the 256x256 one, bit 1 the 256x128 one, 4 disables them.  By default the 256x128 one takes the long-K
+  // problems, where its cheaper K step outweighs its dearer epilogue (measured: tools/epi_probe.py).
   static const int w4 = [] { const char* e = getenv("MVIT_GEMM_W4"); return e ? atoi(e) : 0; }();
   if (huge) return (w4 & 1) ? launch_dense<256, 256, 2, 2>(a, s) : launch_dense<256, 256, 2, 4>(a, s);
-  if (big && dense && (w4 & 2) && (a.N % 128 == 0)) return launch_dense<256, 128, 2, 2>(a, s);
+  if (big && dense && (a.N % 128 == 0) && a.epi != MVIT_EPI_SWIGLU && ((w4 & 2) || (!(w4 & 4) && a.K >= 4096 && a.ksplit <= 1)))
+    return launch_dense<256, 128, 2, 2>(a, s);
   if (a.epi == MVIT_EPI_SWIGLU) {
     if ((a.N % 128) || !dense) return MVIT_EINVAL;
     return big ? launch_dense<256, 128, 4, 2>(a, s) : launch_dense<128, 128, 2, 2>(a, s);

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
   constexpr int SLD = WTN + 4;                // epilogue panel row stride (floats)
   constexpr int SLAB = 16 * SLD;              // 16-row slab per wave
+  constexpr bool PIPE = NW == 4 && WTM == 128;  // one wave per SIMD: register-double-buffered fragment pipeline
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
   static_assert((size_t)NW * SLAB * 4 + (size_t)WAVES_M * BN * 8 <= (size_t)BUF_BYTES, "epilogue panel must fit one LDS buffer");
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   const bf16_t* __restrict__ A2p = (const bf16_t*)p.A2;
   const bf16_t* __restrict__ B2p = (const bf16_t*)p.B2;
 
-  auto make_rsrc = [](const bf16_t* ptr) {
+  auto make_rsrc = [](const bf16_t* ptr) __attribute__((always_inline)) {
     // wave-uniform by construction (kernel arguments + blockIdx arithmetic); readfirstlane makes it provable so the
     // descriptor stays in SGPRs and hipcc does not wrap every buffer_load in a waterfall loop
     const unsigned long long v = (unsigned long long)ptr;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   unsigned baseA = 0, baseB = 0;  // dense operands: this lane's byte offset of chunk row 0 in K tile 0
   int validA = 0, validB = 0;     // bit j: chunk row j lies inside M / N
 
-  auto setup_tile = [&](int vt) {
+  auto setup_tile = [&](int vt) __attribute__((always_inline)) {
     // virtual tile id -> XCD-aware, grouped tile coordinates (bijective for any tile count):
     // block b runs on XCD b%8, so ids congruent mod 8 form one XCD's contiguous chunk of the grouped order
     int wg;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   };
 
   // ---- operand staging: one K tile (A: BM x 64, B: BN x 64) by DMA into LDS buffer `buf`
-  auto issue_tile_impl = [&](int t, int buf, auto ext_tag) {
+  auto issue_tile_impl = [&](int t, int buf, auto ext_tag) __attribute__((always_inline)) {
     constexpr bool ext = decltype(ext_tag)::value;
     char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
     char* b = a + A_BYTES;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // offsets are per-tile constants -> a K step costs LPT x (s_mov m0 + buffer_load), no address VALU at all.
   // (generic lambda on purpose: the DMA builtin only exists for the device target, and the host pass of hipcc must
   // not instantiate the body or it silently drops the kernel's host stub)
-  auto issue_tile_fast = [&](int t, int buf, auto) {
+  auto issue_tile_fast = [&](int t, int buf, auto) __attribute__((always_inline)) {
     char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
     char* b = a + A_BYTES;
     const int soff = t * (BK * 2);
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * RPI * 128), 16, off, soff, 0, 0);
     }
   };
-  auto issue_tile = [&](int t, int buf) {
+  auto issue_tile = [&](int t, int buf) __attribute__((always_inline)) {
     if (AMODE == MVIT_A_DENSE && (t + 1) * BK <= p.K)
       issue_tile_fast(t, buf, 0);
     else if (t < nk1)
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     else
       issue_tile_impl(t, buf, std::true_type{});
   };
-  auto issue_prologue = [&](int first_buf) {
+  auto issue_prologue = [&](int first_buf) __attribute__((always_inline)) {
     int b = first_buf;
 #pragma unroll
     for (int s_ = 0; s_ < NSTAGE - 1; ++s_) {
@@ -265,6 +266,105 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 
     // ---------------------------------------------------------------- main loop
     int ib = cb + NSTAGE - 1 >= NSTAGE ? cb - 1 : cb + NSTAGE - 1;  // buffer receiving K tile t + NSTAGE - 1
+    if constexpr (PIPE) {
+      // One wave per SIMD (4 waves, 128-row sub-tiles): nothing else hides this wave's LDS latency, so the operand
+      // fragments are double-buffered in registers - sub-step s+1 is read while the MFMAs of sub-step s run - and
+      // the K-tile hand-over (wait for the next tile's DMA, barrier, refill of the buffer just consumed, first
+      // fragments of the next tile) sits in front of the LAST sub-step's MFMAs instead of between two K tiles.
+      bf16x8 fa[2][TM], fb[2][TN];
+      // fragment addresses: one lane-dependent offset per sub-step and operand; the 32-row fragment stride (4096 B)
+      // does not touch the swizzle bits and rides on the ds_read immediate
+      unsigned aoff[4], boff[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const unsigned sw = (unsigned)(((s_ * 2 + frag_half) ^ ((frag_row >> 1) & 7)) << 4);
+        aoff[s_] = (unsigned)(wave_m * WTM + frag_row) * 128u + sw;
+        boff[s_] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + frag_row) * 128u + sw;
+      }
+      auto load_frags = [&](const char* a, const char*, int s_, bf16x8 (&xa)[TM], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+        const char* pa = a + aoff[s_];
+        const char* pb = a + boff[s_];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = *(const bf16x8*)(pa + i * 4096);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) xb[j] = *(const bf16x8*)(pb + j * 4096);
+      };
+      auto mma = [&](const bf16x8 (&xa)[TM], const bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i], xb[j], acc[i][j], 0, 0, 0);
+      };
+      auto wait_tile = [&](int tn) __attribute__((always_inline)) {  // this lane's DMA pieces of K tile tn have landed
+        if (NSTAGE == 3 && tn + 1 < t_end)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      };
+      wait_tile(t_begin);
+      __builtin_amdgcn_s_barrier();
+      if (t_begin + NSTAGE - 1 < t_end) issue_tile(t_begin + NSTAGE - 1, ib);
+      load_frags(smem + cb * BUF_BYTES, smem + cb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
+      // `tight` K steps: the refill issued in the step is a full dense tile (straight-line DMA code), so the whole
+      // step is two scheduling regions and the instruction mix is pinned with sched_group_barrier:
+      // one fragment read per two MFMAs in the first three sub-steps, DMA issue + first reads of the next tile
+      // spread over the MFMAs of the last one.
+      auto kstep = [&](int t, auto tight_tag) __attribute__((always_inline)) {
+        constexpr bool tight = decltype(tight_tag)::value;
+        const char* a = smem + cb * BUF_BYTES;
+        const char* b = a + A_BYTES;
+        load_frags(a, b, 1, fa[1], fb[1]);
+        mma(fa[0], fb[0]);
+        load_frags(a, b, 2, fa[0], fb[0]);
+        mma(fa[1], fb[1]);
+        load_frags(a, b, 3, fa[1], fb[1]);
+        mma(fa[0], fb[0]);
+        if constexpr (tight) {
+#pragma unroll
+          for (int g = 0; g < 3 * (TM + TN); ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // 1 LDS read
+            __builtin_amdgcn_sched_group_barrier(0x008, (TM * TN) / (TM + TN), 0);  // MFMAs
+          }
+        }
+        const int nb = cb + 1 == NSTAGE ? 0 : cb + 1;
+        if (tight || t + 1 < t_end) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's last reads of buffer cb are back
+          if constexpr (tight) {
+            if (NSTAGE == 3)
+              asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else {
+            wait_tile(t + 1);
+          }
+          __builtin_amdgcn_s_barrier();
+          if constexpr (tight) {
+            issue_tile_fast(t + NSTAGE, cb, 0);
+          } else {
+            if (t + NSTAGE < t_end) issue_tile(t + NSTAGE, cb);
+          }
+          load_frags(smem + nb * BUF_BYTES, smem + nb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
+        }
+        mma(fa[1], fb[1]);
+        if constexpr (tight) {
+#pragma unroll
+          for (int g = 0; g < TM + TN; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);            // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, LPT / (TM + TN), 1);  // DMA pieces
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);            // LDS read
+            __builtin_amdgcn_sched_group_barrier(0x008, (TM * TN) / (TM + TN) - 1, 1);
+          }
+        }
+        cb = nb;
+      };
+      int t = t_begin;
+      if (AMODE == MVIT_A_DENSE) {
+        const int t_tight = min(t_end, p.K / BK) - NSTAGE;
+        for (; t < t_tight; ++t) kstep(t, std::true_type{});
+      }
+      for (; t < t_end; ++t) kstep(t, std::false_type{});
+    } else {
     for (int t = t_begin; t < t_end; ++t) {
       if (NSTAGE == 3 && t + 1 < t_end)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
@@ -297,6 +397,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       cb = cb + 1 == NSTAGE ? 0 : cb + 1;
       ib = ib + 1 == NSTAGE ? 0 : ib + 1;
     }
+    }
     // every wave is done reading the last K tile: its buffer becomes the epilogue panel, the other NSTAGE-1
     // buffers (starting at cb) receive the first K tiles of the next output tile while the epilogue runs
     __builtin_amdgcn_s_barrier();
@@ -322,7 +423,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     const int lr = lane / CPR, lc = (lane % CPR) * V;
     const int colw = en0 + wave_n * WTN;  // first column of this wave's panel
 
-    auto ld8bf = [&](const bf16_t* q, float (&o)[V], int nv) {
+    auto ld8bf = [&](const bf16_t* q, float (&o)[V], int nv) __attribute__((always_inline)) {
       if (nv == V && !scalar_io) {
         const uint4 t = *(const uint4*)q;
         const uint32_t u[4] = {t.x, t.y, t.z, t.w};
@@ -333,7 +434,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int e = 0; e < V; ++e) o[e] = e < nv ? bf2f(q[e]) : 0.f;
       }
     };
-    auto st8bf = [&](bf16_t* q, const float (&o)[V], int nv) {
+    auto st8bf = [&](bf16_t* q, const float (&o)[V], int nv) __attribute__((always_inline)) {
       if (nv == V && !scalar_io) {
         uint4 t;
         t.x = pack2bf(o[0], o[1]), t.y = pack2bf(o[2], o[3]), t.z = pack2bf(o[4], o[5]), t.w = pack2bf(o[6], o[7]);
@@ -342,7 +443,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int e = 0; e < nv; ++e) q[e] = f2bf(o[e]);
       }
     };
-    auto ld8f = [&](const float* q, float (&o)[V], int nv) {
+    auto ld8f = [&](const float* q, float (&o)[V], int nv) __attribute__((always_inline)) {
       if (nv == V && !scalar_io) {
         const float4 t0 = ((const float4*)q)[0], t1 = ((const float4*)q)[1];
         o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
@@ -351,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int e = 0; e < V; ++e) o[e] = e < nv ? q[e] : 0.f;
       }
     };
-    auto st8f = [&](float* q, const float (&o)[V], int nv) {
+    auto st8f = [&](float* q, const float (&o)[V], int nv) __attribute__((always_inline)) {
       if (nv == V && !scalar_io) {
         ((float4*)q)[0] = make_float4(o[0], o[1], o[2], o[3]);
         ((float4*)q)[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -359,7 +460,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int e = 0; e < nv; ++e) q[e] = o[e];
       }
     };
-    auto panel8 = [&](int rl, int c0, float (&o)[V]) {
+    auto panel8 = [&](int rl, int c0, float (&o)[V]) __attribute__((always_inline)) {
       const float4 t0 = *(const float4*)(stg + rl * SLD + c0), t1 = *(const float4*)(stg + rl * SLD + c0 + 4);
       o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
     };
@@ -390,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     constexpr bool AUX_PF = (EPI == MVIT_EPI_RESID || EPI == MVIT_EPI_DSWIGLU);
     const bool vec_ok = nv == V && !scalar_io;
     uint4 pre[2][NPASS][2];
-    auto issue_aux = [&](int slab, int q) {
+    auto issue_aux = [&](int slab, int q) __attribute__((always_inline)) {
       if constexpr (AUX_PF) {
 #pragma unroll
         for (int it = 0; it < NPASS; ++it) {
@@ -412,7 +513,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         }
       }
     };
-    auto un8bf = [&](const uint4& t, float (&o)[V]) {
+    auto un8bf = [&](const uint4& t, float (&o)[V]) __attribute__((always_inline)) {
       const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);

@@ -130,42 +130,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------ out[M,R] = X[M,K] @ W[R,K]^T, R <= 16
-// LoRA down-projection (x @ A) and its adjoint (dq @ B^T): M is large, R tiny.  One wavefront per 16 rows on
-// v_mfma_f32_16x16x32_bf16 (N = 16 exactly), fragments loaded straight from global memory (X is streamed once,
-// W is L2-resident), 8 k-steps of loads in flight per wave.
-__global__ __launch_bounds__(64) void skinny_xw_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
-                                                       int ldw, bf16_t* __restrict__ out, int ldo, int M, int K, int R) {
-  const int lane = threadIdx.x, r16 = lane & 15, kq = lane >> 4;
+// LoRA down-projection (x @ A) and its adjoint (dq @ B^T): M is large, R tiny.  One block per 16 rows on
+// v_mfma_f32_16x16x32_bf16 (N = 16 exactly); the block's four wavefronts interleave the 32-wide k-steps (M/16 blocks
+// of one wave would leave the chip at ~1 wave per CU, latency-bound), fragments are loaded straight from global memory
+// (X is streamed once, W is L2-resident) with up to 8 k-steps of loads in flight per wave, and the four partial
+// 16x16 blocks are summed through LDS.
+__global__ __launch_bounds__(256) void skinny_xw_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
+                                                        int ldw, bf16_t* __restrict__ out, int ldo, int M, int K, int R) {
+  __shared__ float part[3][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
   const int row = blockIdx.x * 16 + r16;
   const bool rok = row < M, wok = r16 < R;
   const bf16_t* xp = X + (size_t)(rok ? row : 0) * ldx + kq * 8;
   const bf16_t* wp = W + (size_t)(wok ? r16 : 0) * ldw + kq * 8;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const uint4 zero = make_uint4(0, 0, 0, 0);
-  int k = 0;
-  for (; k + 256 <= K; k += 256) {
+  int k = wave * 32;                       // this wave's k-steps: wave, wave + 4, wave + 8, ...
+  for (; k + 7 * 128 + 32 <= K; k += 8 * 128) {
     uint4 xa[8], wb[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      xa[u] = rok ? *(const uint4*)(xp + k + 32 * u) : zero;
-      wb[u] = wok ? *(const uint4*)(wp + k + 32 * u) : zero;
+      xa[u] = rok ? *(const uint4*)(xp + k + 128 * u) : zero;
+      wb[u] = wok ? *(const uint4*)(wp + k + 128 * u) : zero;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&xa[u], *(bf16x8*)&wb[u], acc, 0, 0, 0);
   }
-  for (; k < K; k += 32) {
+  for (; k < K; k += 128) {
     const bool kok = k + kq * 8 < K;
     const uint4 xa = (rok && kok) ? *(const uint4*)(xp + k) : zero;
     const uint4 wb = (wok && kok) ? *(const uint4*)(wp + k) : zero;
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&xa, *(const bf16x8*)&wb, acc, 0, 0, 0);
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wave - 1][lane][j] = acc[j];
+  }
+  __syncthreads();
   // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
-  if (r16 < R) {
+  if (wave == 0 && r16 < R) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int orow = blockIdx.x * 16 + kq * 4 + j;
-      if (orow < M) out[(size_t)orow * ldo + r16] = f2bf(acc[j]);
+      const float v = acc[j] + part[0][lane][j] + part[1][lane][j] + part[2][lane][j];
+      if (orow < M) out[(size_t)orow * ldo + r16] = f2bf(v);
     }
   }
 }
@@ -256,7 +265,7 @@ MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void
                             mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7) || (ldw & 7)) return MVIT_EINVAL;
-  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
+  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
                      (const bf16_t*)W, ldw, (bf16_t*)out, ldo, M, K, R);
   return MVIT_LAUNCH_CHECK();
 }
