@@ -65,6 +65,9 @@ typedef struct mvit_gemm_args {
 } mvit_gemm_args;
 
 MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream);
+/* which tile variant mvit_gemm_bf16 runs for this problem: (BM << 20) | (BN << 8) | (WAVES_M << 4) | WAVES_N
+ * (measurement only: bench.py attributes its HIP-event timings to one kernel instantiation with it) */
+MVIT_API int mvit_gemm_variant(const mvit_gemm_args* args);
 
 /*
  * C(f32)[i*ldci + j*ldcj] += sum_m A[m,i] * B[m,j]: both operands m-major bf16 (the contraction runs over ROWS), MFMA

@@ -42,6 +42,7 @@ class GemmTnArgs(C.Structure):
 # name -> argtypes (restype is always int); mirrors include/miphei_hip.h
 SIGNATURES = {
     "mvit_gemm_bf16": [C.POINTER(GemmArgs), vp],
+    "mvit_gemm_variant": [C.POINTER(GemmArgs)],
     "mvit_gemm_tn_bf16": [C.POINTER(GemmTnArgs), vp],
     "mvit_layernorm_fwd": [vp, vp, vp, vp, ci, ci, cf, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],

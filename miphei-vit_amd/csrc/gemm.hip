@@ -40,8 +40,8 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   return dispatch(al, s);
 }
 
-static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
-  using namespace mvit_gemm;
+// tile variant for a problem: (BM << 20) | (BN << 8) | (WAVES_M << 4) | WAVES_N, or -1
+static int select_variant(const mvit_gemm_args& a) {
   const bool dense = a.amode == MVIT_A_DENSE;
   static const int big_tile = [] { const char* e = getenv("MVIT_GEMM_BIG_TILE"); return e ? atoi(e) : 1; }();
   const bool big = big_tile && a.M >= 1024;  // 8-wave 256x128 tile, 3-stage DMA pipeline
@@ -53,17 +53,35 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   // forces the 256x256 one, bit 1 the 256x128 one, 4 disables them.  By default the 256x128 one takes the long-K
   // problems, where its cheaper K step outweighs its dearer epilogue (measured: tools/epi_probe.py).
   static const int w4 = [] { const char* e = getenv("MVIT_GEMM_W4"); return e ? atoi(e) : 0; }();
-  if (huge) return (w4 & 1) ? launch_dense<256, 256, 2, 2>(a, s) : launch_dense<256, 256, 2, 4>(a, s);
+  auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
+  if (huge) return (w4 & 1) ? id(256, 256, 2, 2) : id(256, 256, 2, 4);
   if (big && dense && (a.N % 128 == 0) && a.epi != MVIT_EPI_SWIGLU && ((w4 & 2) || (!(w4 & 4) && a.K >= 4096 && a.ksplit <= 1)))
-    return launch_dense<256, 128, 2, 2>(a, s);
+    return id(256, 128, 2, 2);
   if (a.epi == MVIT_EPI_SWIGLU) {
-    if ((a.N % 128) || !dense) return MVIT_EINVAL;
-    return big ? launch_dense<256, 128, 4, 2>(a, s) : launch_dense<128, 128, 2, 2>(a, s);
+    if ((a.N % 128) || !dense) return -1;
+    return big ? id(256, 128, 4, 2) : id(128, 128, 2, 2);
   }
-  if (a.N % 128 == 0 || a.N >= 256) {
-    if (big) return dense ? launch_dense<256, 128, 4, 2>(a, s) : launch_conv<256, 128, 4, 2>(a, s);
-    return dense ? launch_dense<128, 128, 2, 2>(a, s) : launch_conv<128, 128, 2, 2>(a, s);
-  }
-  if (a.N > 32) return dense ? launch_dense<128, 64, 2, 2>(a, s) : launch_conv<128, 64, 2, 2>(a, s);
+  if (a.N % 128 == 0 || a.N >= 256) return big ? id(256, 128, 4, 2) : id(128, 128, 2, 2);
+  if (a.N > 32) return id(128, 64, 2, 2);
+  return id(128, 32, 4, 1);
+}
+
+extern "C" MVIT_API int mvit_gemm_variant(const mvit_gemm_args* args) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return MVIT_EINVAL;
+  return select_variant(*args);
+}
+
+static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
+  using namespace mvit_gemm;
+  const bool dense = a.amode == MVIT_A_DENSE;
+  auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
+  const int v = select_variant(a);
+  if (v < 0) return MVIT_EINVAL;
+  if (v == id(256, 256, 2, 2)) return launch_dense<256, 256, 2, 2>(a, s);
+  if (v == id(256, 256, 2, 4)) return launch_dense<256, 256, 2, 4>(a, s);
+  if (v == id(256, 128, 2, 2)) return launch_dense<256, 128, 2, 2>(a, s);
+  if (v == id(256, 128, 4, 2)) return dense ? launch_dense<256, 128, 4, 2>(a, s) : launch_conv<256, 128, 4, 2>(a, s);
+  if (v == id(128, 128, 2, 2)) return dense ? launch_dense<128, 128, 2, 2>(a, s) : launch_conv<128, 128, 2, 2>(a, s);
+  if (v == id(128, 64, 2, 2)) return dense ? launch_dense<128, 64, 2, 2>(a, s) : launch_conv<128, 64, 2, 2>(a, s);
   return dense ? launch_dense<128, 32, 4, 1>(a, s) : launch_conv<128, 32, 4, 1>(a, s);
 }
