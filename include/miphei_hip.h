@@ -149,6 +149,10 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
                                     float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
                                     mvit_stream_t stream);
 /* dst[c][r] = src[r][c] (bf16). */
+/* nn.Conv2d weight [Cout,Cin,3,3] f32 -> the packed bf16 operands of the implicit-GEMM convolution (mipheivit.py:20-31):
+ * wk [Cout, 9*Cp] (forward), wd [Cp, 9*Cout] (dgrad, may be NULL); packed channel c = source channel (c+rot) mod Cin */
+MVIT_API int mvit_pack_conv3x3_weights(const float* W, void* wk, void* wd, int Cout, int Cin, int Cp, int rot,
+                                       mvit_stream_t stream);
 MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int ld_src, long long ld_dst,
                                  mvit_stream_t stream);
 

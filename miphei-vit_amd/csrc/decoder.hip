@@ -251,6 +251,39 @@ inline int nblk(long long work, int per, int cap = 16384) {
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+// ------------------------------------------------------------------ conv weight re-pack (once per optimizer step)
+// W [Cout, Cin, 3, 3] f32 (nn.Conv2d layout)  ->  wk [Cout, 9*Cp] bf16, k = (ky*3+kx)*Cp + c   (B operand of the forward
+// implicit GEMM) and wd [Cp, 9*Cout] bf16, k = (ky*3+kx)*Cout + co (B operand of the dgrad GEMM).  Channel c of the
+// packed layout is source channel (c + rot) mod Cin (fus3 keeps its concat buffer as [up | image]); c >= Cin is zero pad.
+__global__ __launch_bounds__(256) void pack_conv_w_kernel(const float* __restrict__ W, bf16_t* __restrict__ wk,
+                                                          bf16_t* __restrict__ wd, int Cout, int Cin, int Cp, int rot) {
+  const int total = Cout * Cp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int co, c;
+    if (blockIdx.y == 0) {  // c fastest: coalesced wk stores
+      co = i / Cp, c = i - co * Cp;
+    } else {                // co fastest: coalesced wd stores
+      c = i / Cout, co = i - c * Cout;
+    }
+    float v[9];
+    if (c < Cin) {
+      const float* src = W + ((size_t)co * Cin + (c + rot) % Cin) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] = src[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] = 0.f;
+    }
+    if (blockIdx.y == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wk[(size_t)co * 9 * Cp + (size_t)t * Cp + c] = f2bf(v[t]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wd[(size_t)c * 9 * Cout + (size_t)t * Cout + co] = f2bf(v[t]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -325,6 +358,16 @@ MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int 
   if (R <= 0 || Cc <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(transpose_kernel, dim3((R + 63) / 64, (Cc + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, (bf16_t*)dst, R, Cc, ld_src, ld_dst);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_pack_conv3x3_weights(const float* W, void* wk, void* wd, int Cout, int Cin, int Cp, int rot,
+                                       mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (Cout <= 0 || Cin <= 0 || Cp < Cin || (Cp & 7) || rot < 0 || !wk) return MVIT_EINVAL;
+  const int total = Cout * Cp;
+  hipLaunchKernelGGL(pack_conv_w_kernel, dim3(min((total + 255) / 256, 2048), wd ? 2 : 1), dim3(256), 0, (hipStream_t)stream, W,
+                     (bf16_t*)wk, (bf16_t*)wd, Cout, Cin, Cp, rot);
   return MVIT_LAUNCH_CHECK();
 }
 

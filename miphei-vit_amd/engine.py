@@ -284,18 +284,17 @@ class HipEngine:
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
         for i, cv in enumerate(convs):
-            w = f32(cv.conv.weight)                                                 # [Cout, Cin, 3, 3]
+            w = f32(cv.conv.weight).contiguous()                                    # [Cout, Cin, 3, 3]
             cout, cin = w.shape[0], w.shape[1]
-            perm = None
-            if i == len(convs) - 1:                                                 # fus3: internal order [up(64) | img(3)]
-                perm = torch.cat([torch.arange(3, cin), torch.arange(0, 3)]).to(dev)
-                w = w[:, perm]
+            last = i == len(convs) - 1                                              # fus3: internal order [up(64) | img(3)]
+            perm = torch.cat([torch.arange(3, cin), torch.arange(0, 3)]).to(dev) if last else None
             cp = _pad8(cin)
-            wp = torch.zeros(cout, cp, 3, 3, device=dev)
-            wp[:, :cin] = w
-            pk.wk.append(wp.permute(0, 2, 3, 1).reshape(cout, 9 * cp).to(bf).contiguous())
+            wk = torch.empty(cout, 9 * cp, device=dev, dtype=bf)
+            wd = torch.empty(cp, 9 * cout, device=dev, dtype=bf) if need_bwd else None
+            ops.pack_conv3x3_weights(w, wk, wd, rot=3 if last else 0)               # one launch instead of ~10 torch ops
+            pk.wk.append(wk)
             if need_bwd:
-                pk.wd.append(wp.permute(1, 2, 3, 0).reshape(cp, 9 * cout).to(bf).contiguous())
+                pk.wd.append(wd)
             pk.cin.append(cin)
             pk.cin_pad.append(cp)
             pk.perm.append(perm)

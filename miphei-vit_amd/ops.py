@@ -206,6 +206,14 @@ def bn_relu_bwd(dy, ld_dy, x, scale, shift, mean, rstd, gamma, stats, dgamma, db
           _p(dgamma), _p(dbeta), _p(dx), M, C_, nslots, float(M))
 
 
+def pack_conv3x3_weights(W, wk, wd, rot=0):
+    """W [Cout,Cin,3,3] f32 -> wk [Cout, 9*Cp] bf16 (and wd [Cp, 9*Cout] when given); Cp from wk's shape"""
+    assert W.dtype == torch.float32 and W.is_contiguous()
+    cout, cin = W.shape[0], W.shape[1]
+    cp = wk.shape[1] // 9
+    _call("mvit_pack_conv3x3_weights", _p(W), _p(wk), _p(wd), cout, cin, cp, rot)
+
+
 def transpose_bf16(src, dst, R, Cc, ld_src, ld_dst):
     _call("mvit_transpose_bf16", _p(src), _p(dst), R, Cc, ld_src, ld_dst)
 
