@@ -23,6 +23,7 @@ import torch.distributed as dist  # noqa: E402
 
 FLOPS_TRAIN = {256: 1647.2e9, 512: 7604.0e9}   # SURVEY.md section 8(d), per tile
 FLOPS_FWD = {256: 793.4e9, 512: 3449.1e9}
+FLOPS_ENC = {256: 773.6e9}                       # encoder only (patch embed + 40 blocks)
 PEAK_BF16 = 2.5e15                                # dense MFMA bf16, MI355X_MICROARCH.md
 
 
@@ -76,7 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (cfg.train.batch_size of the reference)")
     ap.add_argument("--img", type=int, default=256)
-    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--mode", choices=["train", "infer", "embed"], default="train",
+                    help="embed = encoder-only class-token embeddings (SURVEY.md 8f row 4, extract_embeddings.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -109,8 +111,14 @@ def main():
     nc = 16
     weights = torch.tensor([1.0, 6.9687, 1.4698, 3.5986, 2.4121, 10.5982, 4.4980, 2.7238, 4.5266, 3.0473, 2.8660, 3.5367,
                             1.7173, 3.6613, 1.5315, 2.5265])
+    if a.mode == "embed":
+        from miphei_vit_amd.generators.foundation_models import FOUNDATION_MODEL_REGISTRY
+        with torch.device(dev):
+            emb_model = FOUNDATION_MODEL_REGISTRY[a.encoder](a.img, pretrained=False, global_pool="token")
+        synthetic_init_(emb_model, seed=0)
+        emb_model = emb_model.eval().half()
     with torch.device(dev):
-        model = get_vitmatte(a.encoder, a.img, nc, use_lora=True, pretrained=False)
+        model = get_vitmatte("tiny" if a.mode == "embed" else a.encoder, a.img, nc, use_lora=True, pretrained=False)
     synthetic_init_(model, seed=0)
     eng = model._engine
     mod = ModelModule(model, None, 2e-4 * a.batch ** 0.5, 0., WeightedMSELoss(50.0, weights)).to(dev)
@@ -123,6 +131,7 @@ def main():
     batches = [synthetic_batch(1234 + rank * 1000 + i, a.batch, a.img, nc, dev) for i in range(4)]
 
     lat = []
+    x16 = [b[0].half() for b in batches] if a.mode == "embed" else None
     if a.mode == "infer":
         model.eval()
         run_graph, x_static, _ = eng.capture_inference(a.batch) if a.graph else (None, None, None)
@@ -131,6 +140,9 @@ def main():
         x, y = batches[i % len(batches)]
         if a.mode == "train":
             mod.training_step({"image": x, "target": y}, i)
+        elif a.mode == "embed":
+            with torch.no_grad():
+                emb_model(x16[i % len(batches)])
         elif a.graph:
             x_static.copy_(x)      # device-to-device; the tile batch is already resident
             run_graph()
@@ -159,16 +171,18 @@ def main():
         dt = float(t)
     tiles = world * a.batch * a.steps
     value = tiles / dt
-    flops_tile = (FLOPS_TRAIN if a.mode == "train" else FLOPS_FWD).get(a.img)
+    flops_tile = (FLOPS_TRAIN if a.mode == "train" else FLOPS_ENC if a.mode == "embed" else FLOPS_FWD).get(a.img)
 
     cfg_idx = (1 if a.img == 256 else 3) if a.mode == "train" else 4
     res = {
-        "metric": f"training tiles/sec ({a.img}x{a.img} H&E->16ch mIF)" if a.mode == "train" else "inference tiles/sec",
+        "metric": (f"training tiles/sec ({a.img}x{a.img} H&E->16ch mIF)" if a.mode == "train" else
+                   "embedding tiles/sec (encoder only, class token, fp16 in/out)" if a.mode == "embed" else "inference tiles/sec"),
         "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) {a.mode} step, "
-                               f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} (BASELINE.json configs[{cfg_idx}])",
+                               f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} " +
+                               ("(SURVEY.md 8f row 4)" if a.mode == "embed" else f"(BASELINE.json configs[{cfg_idx}])"),
                    "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}"},
     }
     if a.mode == "infer":

@@ -82,7 +82,8 @@ class HipEngine:
         lora = hasattr(qkv0, "lora_q")
         c = NS(D=vit.embed_dim, L=len(vit.blocks), H=vit.num_heads, patch=vit.patch_embed.patch_size[0], grid=g[0], S=S[0],
                nreg=vit.reg_tokens, prefix=vit.num_prefix_tokens, swiglu=vit.mlp_type == "swiglu", hidden=vit.hidden,
-               eps=vit.ln_eps, lora=lora, NH=self.model.decoder.num_heads)
+               eps=vit.ln_eps, lora=lora, dec=getattr(self.model, "decoder", None) is not None)
+        c.NH = self.model.decoder.num_heads if c.dec else 0
         c.Dh = c.D // c.H
         c.ntok = c.grid * c.grid + c.prefix
         c.Hg = c.hidden // 2 if c.swiglu else c.hidden
@@ -243,9 +244,9 @@ class HipEngine:
     def _pack_trainable(self, need_bwd):
         c = self._config()
         dev = self._require_gpu()
-        dec = self.model.decoder
+        dec = getattr(self.model, "decoder", None)
         vit = self.model.encoder.vit
-        params = list(dec.parameters()) + ([p for blk in vit.blocks for p in blk.attn.qkv.lora_q.parameters()] +
+        params = (list(dec.parameters()) if dec is not None else [vit.pos_embed, vit.cls_token]) + ([p for blk in vit.blocks for p in blk.attn.qkv.lora_q.parameters()] +
                                            [p for blk in vit.blocks for p in blk.attn.qkv.lora_v.parameters()] if c.lora else [])
         key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:4]), need_bwd)
         if self._pack_key == key:
@@ -281,6 +282,9 @@ class HipEngine:
             if need_bwd:
                 pk.Acat16 = pk.Acat.to(bf)                                          # B2 operand of the dh1 GEMM
                 pk.Bq16, pk.Bv16 = (c.alpha * Bq).to(bf).contiguous(), (c.alpha * Bv).to(bf).contiguous()  # [L, r, D]
+        if dec is None:   # encoder-only engine (bare registry model: embedding extraction)
+            self._pack_key, self._pack = key, pk
+            return pk
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
         for i, cv in enumerate(convs):
@@ -342,6 +346,11 @@ class HipEngine:
         w.u = [e(M, c.hidden) for _ in range(nl)] if train else None
         w.g = e(M, c.Hg)
         w.tok = e(M, D)
+        if not c.dec:
+            if train:
+                raise NotImplementedError("the encoder-only engine is inference-only")
+            self._ws[key] = w
+            return w
         G = S // 16
         s1, s2, s3 = S // 2, S // 4, S // 8
         w.res = (S, s1, s2, s3, G)
@@ -768,15 +777,30 @@ class _GeneratorFn(torch.autograd.Function):
         return (None, None, *grads)
 
 
+class _BareEncoder(torch.nn.Module):
+    """Engine owner of a registry model used outside ViTMatte (embedding extraction: `FOUNDATION_MODEL_REGISTRY[name](...)`
+    called directly, reference preprocessings/artifacts_detection/extract_embeddings.py:41-42): `.encoder.vit`, no decoder."""
+
+    def __init__(self, vit):
+        super().__init__()
+        object.__setattr__(self, "encoder", NS(vit=vit))
+
+    def parameters(self, recurse=True):
+        return self.encoder.vit.parameters(recurse)
+
+
 def encoder_tokens(vit, x):
-    """Encoder-only forward for a bare VisionTransformer (registry models used outside ViTMatte)."""
+    """Encoder-only forward for a bare VisionTransformer: final-norm tokens [B, N, D] in fp32."""
     eng = vit.__dict__.get("_engine_owner")
     if eng is None:
-        raise RuntimeError("encoder-only forward needs the ViT to be wrapped by ViTMatte (engine owner)")
+        eng = HipEngine(_BareEncoder(vit))
+        object.__setattr__(vit, "_engine_owner", eng)
     dev = eng._require_gpu()
     x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+    c = eng._config()
+    if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != c.S or x.shape[3] != c.S:
+        raise ValueError(f"expected [B,3,{c.S},{c.S}] input, got {tuple(x.shape)}")
     pk = eng._pack_trainable(need_bwd=False)
     w = eng._workspace(x.shape[0], False)
-    c = eng._config()
     tok = eng._encoder_fwd(w, x, False, pk)
     return tok.view(x.shape[0], c.ntok, c.D).float()

@@ -111,9 +111,19 @@ class VisionTransformer(nn.Module):
             eng.invalidate()
 
     def forward(self, x):
-        """Encoder-only tokens [B, N, D] (global_pool='', no head) through the HIP engine."""
+        """timm `forward` with num_classes=0 through the HIP engine: final-norm tokens, pooled per `global_pool`
+        ('' -> [B, N, D]; 'token' -> class token [B, D]; 'avg' -> mean of the patch tokens [B, D]).  The embedding
+        extraction script of the reference calls the registry model this way with global_pool='token' on fp16 inputs
+        (preprocessings/artifacts_detection/extract_embeddings.py:41-42,78); the result keeps the input dtype."""
         from ..engine import encoder_tokens
-        return encoder_tokens(self, x)
+        tok = encoder_tokens(self, x)
+        if self.global_pool == "token":
+            tok = tok[:, 0]
+        elif self.global_pool == "avg":
+            tok = tok[:, self.num_prefix_tokens:].mean(dim=1)
+        elif self.global_pool != "":
+            raise NotImplementedError(f"global_pool={self.global_pool!r}")
+        return tok.to(x.dtype) if x.is_floating_point() else tok
 
 
 def _resample_pos_embed(posemb, old_grid, new_grid):

@@ -160,3 +160,27 @@ def test_half_precision_eval_convention():
         ref = generator_forward(p, x, cfg, 3, training=False)
     assert out.dtype == torch.float16
     assert float(_chan_rel_mse(out.float().cpu(), ref).max()) < 2e-3   # fp16-rounded parameters + bf16 compute
+
+
+@pytest.mark.parametrize("cfgname,img,pool", [("tiny_swiglu", 126, "token"), ("tiny", 128, "avg"), ("tiny", 128, "")])
+def test_registry_model_embeddings(cfgname, img, pool):
+    """encoder-only embedding extraction: FOUNDATION_MODEL_REGISTRY[name](img, global_pool=...).eval().cuda().half() called
+    on half inputs (reference preprocessings/artifacts_detection/extract_embeddings.py:41-42,78) vs the fp32 oracle ViT."""
+    from oracle import VIT_CONFIGS, det_state_dict
+    from oracle.vit import vit_forward, vit_state_shapes
+    from miphei_vit_amd.generators.foundation_models import FOUNDATION_MODEL_REGISTRY
+    cfg = VIT_CONFIGS[cfgname]
+    sd = det_state_dict(vit_state_shapes(cfg, img, prefix="", lora=False), seed=5, layerscale=0.5)
+    p = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    model = FOUNDATION_MODEL_REGISTRY[cfgname](img, pretrained=False, global_pool=pool)
+    model.load_state_dict(p)
+    model = model.eval().cuda().half()
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((3, 3, img, img)).astype(np.float32))
+    with torch.no_grad():
+        got = model(x.cuda().half())
+        tok = vit_forward(p, x.half().float(), cfg, prefix="", lora=False)
+    ref = tok[:, 0] if pool == "token" else tok[:, 5:].mean(1) if pool == "avg" else tok
+    assert got.dtype == torch.float16 and got.shape == ref.shape
+    assert _rel(got.float(), ref) < 2e-2      # bf16 operands / fp16-rounded parameters vs fp32
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, img + 14, img + 14).cuda().half())
