@@ -82,6 +82,11 @@ typedef struct mvit_gemm_tn_args {
   long long ldci, ldcj;
   int M, I, J, lda, ldb, amode, msplit;
   int conv_H, conv_W, conv_C, conv_ld, conv_OH, conv_OW, conv_stride;
+  /* optional second output from the same pass (NULL = off): rows i >= isplit go to C2[(i-isplit), ...].  With jlo2 > 0
+   * the columns are split too: rows < isplit keep columns j < j1 (in C), rows >= isplit keep columns j >= jlo2
+   * (C2, column j - jlo2), everything else is dropped - the two LoRA adapters' dB from one pass over [dq | dk | dv]. */
+  float* C2;
+  int isplit, j1, jlo2, pad_;
 } mvit_gemm_tn_args;
 MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_stream_t stream);
 
@@ -99,6 +104,9 @@ MVIT_API int mvit_layernorm_bwd(const void* dh_bf16, const float* x, const float
  * LoRALayer.forward x @ A (src/generators/lora.py:16-18) and its adjoint dq @ B^T. */
 MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void* out, int ldo, int M, int K, int R,
                             mvit_stream_t stream);
+/* two such products of one shape in one launch (the q and v adapters' dt = dq @ B_q^T, dv @ B_v^T) */
+MVIT_API int mvit_skinny_xw2(const void* X0, const void* W0, void* out0, const void* X1, const void* W1, void* out1, int ldx,
+                             int ldw, int ldo, int M, int K, int R, mvit_stream_t stream);
 /* NCHW f32 image -> bf16 patch matrix [B*g*g, Kp], k = c*p*p + iy*p + ix (timm PatchEmbed conv k=s=p). */
 MVIT_API int mvit_im2col_patch(const float* img, void* out_bf16, int B, int S, int p, int g, int Kp, mvit_stream_t stream);
 /* x[b,0]=cls, x[b,1..R]=reg  (timm _pos_embed with no_embed_class=True). */

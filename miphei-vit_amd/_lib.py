@@ -36,7 +36,7 @@ class GemmTnArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("ldci", ll), ("ldcj", ll),
                 ("M", ci), ("I", ci), ("J", ci), ("lda", ci), ("ldb", ci), ("amode", ci), ("msplit", ci),
                 ("conv_H", ci), ("conv_W", ci), ("conv_C", ci), ("conv_ld", ci), ("conv_OH", ci), ("conv_OW", ci),
-                ("conv_stride", ci)]
+                ("conv_stride", ci), ("C2", vp), ("isplit", ci), ("j1", ci), ("jlo2", ci), ("pad_", ci)]
 
 
 # name -> argtypes (restype is always int); mirrors include/miphei_hip.h
@@ -47,6 +47,7 @@ SIGNATURES = {
     "mvit_layernorm_fwd": [vp, vp, vp, vp, ci, ci, cf, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
     "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
+    "mvit_skinny_xw2": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "mvit_im2col_patch": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_prefix_tokens": [vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_cast_f32_bf16": [vp, vp, C.c_longlong, vp],

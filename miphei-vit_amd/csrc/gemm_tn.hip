@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
   const long long per = (nsteps + gridDim.z - 1) / gridDim.z;
   const long long s_begin = blockIdx.z * per, s_end = min(nsteps, s_begin + per);
   if (s_begin >= s_end) return;
+  if (p.C2 && p.jlo2 > 0 && j0 >= p.j1 && j0 + JT <= p.jlo2) return;  // column block owned by neither output
   const bf16_t* Ap = (const bf16_t*)p.A;
   const bf16_t* Bp = (const bf16_t*)p.B;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(AMODE == MVIT_A_DENSE ? (const void*)(Ap + (size_t)s_begin * 64 * p.lda) : (const void*)Ap);
@@ -151,7 +152,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = i0 + il + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (i < p.I) atomicAdd(C + (size_t)i * p.ldci + (size_t)j * p.ldcj, acc[t][r]);
+      if (i >= p.I) continue;
+      if (!p.C2) {
+        atomicAdd(C + (size_t)i * p.ldci + (size_t)j * p.ldcj, acc[t][r]);
+      } else if (i < p.isplit) {   // two outputs from one pass (see mvit_gemm_tn_args)
+        if (p.jlo2 == 0 || j < p.j1) atomicAdd(C + (size_t)i * p.ldci + (size_t)j * p.ldcj, acc[t][r]);
+      } else if (j >= p.jlo2) {
+        atomicAdd(p.C2 + (size_t)(i - p.isplit) * p.ldci + (size_t)(j - p.jlo2) * p.ldcj, acc[t][r]);
+      }
     }
   }
 }
@@ -177,6 +185,7 @@ extern "C" MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_st
   if (!args) return MVIT_EINVAL;
   const mvit_gemm_tn_args& a = *args;
   if (a.M <= 0 || a.I <= 0 || a.J <= 0 || (a.I & 7) || (a.J & 7) || (a.ldb & 7)) return MVIT_EINVAL;
+  if (a.C2 && (a.isplit <= 0 || a.isplit >= a.I || a.jlo2 < 0 || (a.jlo2 > 0 && (a.j1 <= 0 || a.j1 > a.jlo2)))) return MVIT_EINVAL;
   if (a.amode == MVIT_A_DENSE) {
     if (a.lda & 7) return MVIT_EINVAL;
   } else if (a.amode == MVIT_A_CONV3) {

@@ -135,8 +135,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // of one wave would leave the chip at ~1 wave per CU, latency-bound), fragments are loaded straight from global memory
 // (X is streamed once, W is L2-resident) with up to 8 k-steps of loads in flight per wave, and the four partial
 // 16x16 blocks are summed through LDS.
-__global__ __launch_bounds__(256) void skinny_xw_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
-                                                        int ldw, bf16_t* __restrict__ out, int ldo, int M, int K, int R) {
+struct SkinnyPair {
+  const bf16_t* X[2];
+  const bf16_t* W[2];
+  bf16_t* out[2];
+};
+__global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int ldx, int ldw, int ldo, int M, int K, int R) {
+  const bf16_t* __restrict__ X = pr.X[blockIdx.y];
+  const bf16_t* __restrict__ W = pr.W[blockIdx.y];
+  bf16_t* __restrict__ out = pr.out[blockIdx.y];
   __shared__ float part[3][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
   const int row = blockIdx.x * 16 + r16;
@@ -265,8 +272,17 @@ MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void
                             mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7) || (ldw & 7)) return MVIT_EINVAL;
-  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
-                     (const bf16_t*)W, ldw, (bf16_t*)out, ldo, M, K, R);
+  SkinnyPair pr{{(const bf16_t*)X, nullptr}, {(const bf16_t*)W, nullptr}, {(bf16_t*)out, nullptr}};
+  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16, 1), dim3(256), 0, (hipStream_t)stream, pr, ldx, ldw, ldo, M, K, R);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_skinny_xw2(const void* X0, const void* W0, void* out0, const void* X1, const void* W1, void* out1, int ldx,
+                             int ldw, int ldo, int M, int K, int R, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7) || (ldw & 7) || !X1 || !W1 || !out1) return MVIT_EINVAL;
+  SkinnyPair pr{{(const bf16_t*)X0, (const bf16_t*)X1}, {(const bf16_t*)W0, (const bf16_t*)W1}, {(bf16_t*)out0, (bf16_t*)out1}};
+  hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16, 2), dim3(256), 0, (hipStream_t)stream, pr, ldx, ldw, ldo, M, K, R);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -702,14 +702,15 @@ class HipEngine:
             ops.gemm(w.dy, b.t.wproj, w.do)
             ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, w.dqkv, B, c.ntok, c.H, c.Dh, scale)
             dq, dv = w.dqkv, w.dqkv.view(-1)[2 * D:]
-            ops.skinny_xw(dq, pk.Bq16[l], w.dt, ldx=3 * D, ldo=2 * r_, M=M)                    # dt_q = dq @ (a B_q)^T
-            ops.skinny_xw(dv, pk.Bv16[l], w.dt.view(-1)[r_:], ldx=3 * D, ldo=2 * r_, M=M)      # dt_v = dv @ (a B_v)^T
+            # dt_q = dq @ (a B_q)^T, dt_v = dv @ (a B_v)^T: one launch
+            ops.skinny_xw2(dq, pk.Bq16[l], w.dt, dv, pk.Bv16[l], w.dt.view(-1)[r_:], ldx=3 * D, ldw=D, ldo=2 * r_, M=M, K=D, R=r_)
             t = w.t[l]
-            # LoRA weight gradients on the TN MFMA GEMM: dB = t^T dq (rows of B), dA = (dt^T h)^T (columns of A)
-            ops.gemm_tn(t, dq, fl.dBq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
-            ops.gemm_tn(t.view(-1)[r_:], dv, fl.dBv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit)
-            ops.gemm_tn(w.dt, w.h1[l], fl.dAq[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
-            ops.gemm_tn(w.dt.view(-1)[r_:], w.h1[l], fl.dAv[l], M=M, I=r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit)
+            # LoRA weight gradients on the TN MFMA GEMM, both adapters per pass: dB = t^T [dq | . | dv] (rows of B_q from
+            # the q columns, rows of B_v from the v columns), dA = ([dt_q | dt_v]^T h)^T (columns of A_q, A_v)
+            ops.gemm_tn(t, w.dqkv, fl.dBq[l], M=M, I=2 * r_, J=3 * D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit,
+                        c2=fl.dBv[l], isplit=r_, j1=D, jlo2=2 * D)
+            ops.gemm_tn(w.dt, w.h1[l], fl.dAq[l], M=M, I=2 * r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit,
+                        c2=fl.dAv[l], isplit=r_)
             if l > 0:
                 ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
                 ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)

@@ -99,8 +99,10 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     return c
 
 
-def gemm_tn(a, b, c, *, M, I, J, lda=None, ldb=None, ldci=None, ldcj=1, msplit=1, conv=None):
-    """C[i,j] (f32, += ) = sum_m A[m,i] * B[m,j]; conv=(H, W, C, ld, OH, OW, stride) makes A the virtual im2col."""
+def gemm_tn(a, b, c, *, M, I, J, lda=None, ldb=None, ldci=None, ldcj=1, msplit=1, conv=None, c2=None, isplit=0, j1=0,
+            jlo2=0):
+    """C[i,j] (f32, += ) = sum_m A[m,i] * B[m,j]; conv=(H, W, C, ld, OH, OW, stride) makes A the virtual im2col.
+    c2/isplit(/j1/jlo2): second output from the same pass (rows >= isplit, optionally columns >= jlo2), see the header."""
     _chk_bf16(a, "A")
     _chk_bf16(b, "B")
     assert c.dtype == torch.float32
@@ -111,6 +113,9 @@ def gemm_tn(a, b, c, *, M, I, J, lda=None, ldb=None, ldci=None, ldcj=1, msplit=1
     g.ldci = ldci if ldci is not None else c.stride(0)
     g.ldcj = ldcj
     g.msplit = msplit
+    if c2 is not None:
+        assert c2.dtype == torch.float32
+        g.C2, g.isplit, g.j1, g.jlo2 = c2.data_ptr(), isplit, j1, jlo2
     if conv is None:
         g.amode, g.lda = A_DENSE, lda if lda is not None else a.stride(0)
     else:
@@ -143,6 +148,13 @@ def skinny_xw(X, W, out, *, ldx=None, ldw=None, ldo=None, M=None, K=None, R=None
     _call("mvit_skinny_xw", _p(X), ldx or X.stride(0), _p(W), ldw or W.stride(0), _p(out), ldo or out.stride(0),
           M or X.shape[0], K or W.shape[1], R or W.shape[0])
     return out
+
+
+def skinny_xw2(X0, W0, out0, X1, W1, out1, *, ldx, ldw, ldo, M, K, R):
+    """two skinny products out_i[M,R] = X_i[M,K] @ W_i[R,K]^T of the same shape in one launch"""
+    for t in (X0, W0, X1, W1):
+        _chk_bf16(t, "operand")
+    _call("mvit_skinny_xw2", _p(X0), _p(W0), _p(out0), _p(X1), _p(W1), _p(out1), ldx, ldw, ldo, M, K, R)
 
 
 def im2col_patch(img, out, patch, grid):

@@ -176,6 +176,15 @@ def test_gemm_tn_dense(M, I, J):
     c3 = torch.zeros(8, 104, device="cuda")
     ops.gemm_tn(aw.view(-1)[8:], bw.view(-1)[2 * 104:], c3, M=M, I=8, J=104, lda=16, ldb=3 * 104, msplit=3)
     assert _rel(c3, aw[:, 8:].float().t() @ bw[:, 208:].float()) < 1e-5
+    # two outputs from one pass: row split (both adapters' dA) and row+column split (both adapters' dB)
+    full = aw.float().t() @ bw.float()                      # [16, 312]
+    d0, d1 = torch.zeros(104, 8, device="cuda"), torch.zeros(104, 8, device="cuda")
+    ops.gemm_tn(aw, bw, d0, M=M, I=16, J=104, lda=16, ldb=3 * 104, ldci=1, ldcj=8, msplit=2, c2=d1, isplit=8)
+    assert _rel(d0, full[:8, :104].t()) < 1e-5 and _rel(d1, full[8:, :104].t()) < 1e-5
+    e0, e1 = torch.zeros(8, 104, device="cuda"), torch.zeros(8, 104, device="cuda")
+    ops.gemm_tn(aw, bw, e0, M=M, I=16, J=3 * 104, lda=16, ldb=3 * 104, ldci=104, ldcj=1, msplit=2, c2=e1, isplit=8, j1=104,
+                jlo2=2 * 104)
+    assert _rel(e0, full[:8, :104]) < 1e-5 and _rel(e1, full[8:, 208:]) < 1e-5
 
 
 @pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),

@@ -59,6 +59,12 @@ def test_skinny():
     out2 = torch.zeros(M, 16, device="cuda", dtype=torch.bfloat16)
     ops.skinny_xw(Xw.view(-1)[2 * 104:], Bm, out2.view(-1)[8:], ldx=3 * 104, ldo=16, M=M)
     assert _rel(out2[:, 8:].float(), Xw[:, 208:].float() @ Bm.float().t()) < 4e-3 and float(out2[:, :8].abs().max()) == 0
+    # the paired launch (both LoRA adapters): q columns -> out[:, :8], v columns -> out[:, 8:]
+    Bq = _rand(8, 104, seed=4, scale=0.1).bfloat16()
+    out3 = torch.zeros(M, 16, device="cuda", dtype=torch.bfloat16)
+    ops.skinny_xw2(Xw, Bq, out3, Xw.view(-1)[2 * 104:], Bm, out3.view(-1)[8:], ldx=3 * 104, ldw=104, ldo=16, M=M, K=104, R=8)
+    assert _rel(out3[:, :8].float(), Xw[:, :104].float() @ Bq.float().t()) < 4e-3
+    assert _rel(out3[:, 8:].float(), Xw[:, 208:].float() @ Bm.float().t()) < 4e-3
 
 
 def test_patch_prefix_cast():
