@@ -239,36 +239,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
   }
 }
 
-// ------------------------------------------------------------------ backward, preparation: D[b,h,q] = sum_d dO*O
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO,
-                                                            float* __restrict__ Dv, AttnDims dm) {
-  // one thread per (b, q, h)
-  const long long total = (long long)dm.B * dm.N * dm.H;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int h = (int)(i % dm.H);
-  const long long bq = i / dm.H;
-  const int qq = (int)(bq % dm.N), b = (int)(bq / dm.N);
-  const bf16_t* po = o + (size_t)i * dm.Dh;
-  const bf16_t* pd = dO + (size_t)i * dm.Dh;
-  float s = 0.f;
-  for (int d = 0; d < dm.Dh; d += 8) {
-    const uint4 a = *(const uint4*)(po + d), c = *(const uint4*)(pd + d);
-    const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, uc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s += __uint_as_float(ua[j] << 16) * __uint_as_float(uc[j] << 16);
-      s += __uint_as_float(ua[j] & 0xffff0000u) * __uint_as_float(uc[j] & 0xffff0000u);
-    }
-  }
-  Dv[((size_t)b * dm.H + h) * dm.N + qq] = s;
-}
-
 // ------------------------------------------------------------------ backward, dQ (query-stationary, S^T form)
 //   S^T = K Q^T, P = exp(S*scale - L), dP^T = V dO^T, dS^T = P*(dP^T - D)*scale, dQ^T += K^T dS^T
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
-                                                          const float* __restrict__ lse, const float* __restrict__ Dv,
-                                                          bf16_t* __restrict__ dqkv, AttnDims dm) {
+// D[b,h,q] = sum_d dO*O is formed here from the rows this lane already holds (O is one more 16-byte load per chunk)
+// and stored for the dK/dV kernel, which runs after this one: no separate preparation pass.
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                          const bf16_t* __restrict__ dO, const float* __restrict__ lse,
+                                                          float* __restrict__ Dv, bf16_t* __restrict__ dqkv, AttnDims dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -282,19 +259,29 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
   const int q = blockIdx.x * 128 + wave * 32 + l31;
 
   bf16x8 qf[4], dof[4];
+  float dsum = 0.f;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int d = 16 * s + 8 * half;
-    uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+    uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
     if (q < N && d < Dh) {
       t = *(const uint4*)(qb + (size_t)q * rs + d);
       u = *(const uint4*)(dob + (size_t)q * ors + d);
+      ov = *(const uint4*)(o + (size_t)b * N * ors + (size_t)h * Dh + (size_t)q * ors + d);
     }
     qf[s] = *(bf16x8*)&t;
     dof[s] = *(bf16x8*)&u;
+    const uint32_t ua[4] = {ov.x, ov.y, ov.z, ov.w}, uc[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dsum += __uint_as_float(ua[j] << 16) * __uint_as_float(uc[j] << 16);
+      dsum += __uint_as_float(ua[j] & 0xffff0000u) * __uint_as_float(uc[j] & 0xffff0000u);
+    }
   }
+  dsum += __shfl_xor(dsum, 32, 64);  // the other half of the head dimension
   const float Lq = q < N ? lse[(size_t)bh * N + q] * LOG2E : 0.f;
-  const float Dq = q < N ? Dv[(size_t)bh * N + q] : 0.f;
+  const float Dq = dsum;
+  if (half == 0 && q < N) Dv[(size_t)bh * N + q] = dsum;
   const float sc = dm.scale * LOG2E;
 
   f32x16 dqacc[2];
@@ -536,11 +523,8 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
   hipStream_t s = (hipStream_t)stream;
-  const long long tot = (long long)B * N * H;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
-                     (const bf16_t*)d_out, dsum, dm);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
-                     (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
+                     (const bf16_t*)out, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;
   static size_t lds_raised = 64 * 1024;  // grow-only: the attribute is a per-function maximum
   if (lds_kv > lds_raised) {
