@@ -184,3 +184,33 @@ def test_registry_model_embeddings(cfgname, img, pool):
     assert _rel(got.float(), ref) < 2e-2      # bf16 operands / fp16-rounded parameters vs fp32
     with pytest.raises(ValueError):
         model(torch.zeros(1, 3, img + 14, img + 14).cuda().half())
+
+
+@pytest.mark.parametrize("cfgname,img,nc,B", [("tiny", 128, 1, 1), ("tiny_swiglu", 126 + 2, 5, 3), ("tiny", 256, 16, 1)])
+def test_edge_shapes_forward_backward(cfgname, img, nc, B):
+    """single-tile batches (train-mode BatchNorm over one sample), a single marker head, odd batch / head counts:
+    forward vs the fp32 oracle and a full backward that must stay finite and close on the head / decoder parameters."""
+    from oracle import generator_forward, synth_batch, weighted_mse_loss
+    from oracle.model import OracleTrainer, orion_marker_weights
+    cfg, p, model = _load(cfgname, img, nc, 21)
+    x, y = synth_batch(21, B, img, nc)
+    w = orion_marker_weights(16)[:nc]
+    model.train()
+    out = model(x.cuda())
+    ref = generator_forward(p, x, cfg, nc, training=True)
+    assert float(_chan_rel_mse(out.detach().float().cpu(), ref).max()) < REL_MSE
+    loss = weighted_mse_loss(y.cuda(), out, w.cuda())
+    loss.backward()
+    tr = OracleTrainer(p, cfg, nc, batch_size=B, total_iters=100, weights=w)
+    _, loss_ref, gref = tr.loss_and_grads(x, y)
+    assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref))
+    named = dict(model.named_parameters())
+    gnorm = float(torch.cat([g.flatten().double() for g in gref.values()]).norm())
+    for k, gr in gref.items():
+        got = named[k].grad
+        assert got is not None and bool(torch.isfinite(got).all()), k
+        if k.startswith("decoder.") and float(gr.double().norm()) > 1e-3 * gnorm:
+            # bf16-operand noise grows with depth (5-19 % on the first ConvStream conv, the same as the reference's own
+            # bf16 autocast mode - see test_backward_matches_oracle_autograd for the yardstick); heads are shallow
+            tol = 0.1 if k.startswith("decoder.segmentation_head") else 0.35
+            assert _rel(got, gr) < tol, (k, _rel(got, gr))
