@@ -312,47 +312,118 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const bf16_t* __restri
   }
 }
 
-// ------------------------------------------------------------------ gated 3x3 conv + tanh (thread per pixel)
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G,
+// ------------------------------------------------------------------ gated 3x3 conv + tanh, on MFMA
+// y[p,h] = tanh(b3[h] + sum_d g[q_d,h] * T[q_d,(d,h)]),  T[q,(d,h)] = W3[h,d,:] . x[q,:],  q_d = p + offset(d).
+// A block walks 4 x 32 pixel tiles: T for the tile plus its one-pixel halo (204 pixels = 7 MFMA pixel tiles, five
+// 32-row (d,h) blocks each, W3 as bf16 hi+lo pairs) is formed once per pixel instead of once per (pixel, head, tap);
+// the gated products are parked in LDS in fp32 and every output pixel sums its nine shifted entries.  The x / gate
+// rows of the next tile are loaded before the current one is computed.
+constexpr int CF_TH = 4, CF_TW = 32;
+constexpr int CF_RW = CF_TW + 2, CF_RH = CF_TH + 2, CF_NR = CF_RH * CF_RW, CF_NT = (CF_NR + 31) / 32;
+constexpr int CF_PS = 592;  // bytes per halo pixel: 9 taps x 16 heads fp32 (576) + pad -> conflict-free 16-byte stores
+constexpr int CF_LDS = CF_NT * 32 * CF_PS;
+static_assert(CF_NT <= 8, "one MFMA pixel tile per wave");
+
+struct CfIn {
+  Frag x0, x1;
+  uint4 g;
+};
+// tanh through one exp and one reciprocal (|err| ~ 1e-7 relative on (-1, 1); saturates cleanly for large |y|)
+__device__ __forceinline__ float fast_tanh(float y) {
+  const float e = __expf(2.f * fminf(fmaxf(y, -15.f), 15.f));
+  return 1.f - 2.f / (e + 1.f);
+}
+
+__global__ __launch_bounds__(512) void conv_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ G,
                                                        const float* __restrict__ W3, const float* __restrict__ b3,
                                                        float* __restrict__ out, int B, int H, int W, int NH) {
-  __shared__ __attribute__((aligned(16))) float w3s[MAXH * 9 * XC];
-  for (int e = threadIdx.x; e < NH * 9 * XC; e += 256) w3s[e] = W3[e];
-  __syncthreads();
-  const long long M = (long long)B * H * W;
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < M; p += (long long)gridDim.x * 256) {
-    const int px = (int)(p % W);
-    const long long t = p / W;
-    const int py = (int)(t % H), b = (int)(t / H);
-    float y[MAXH];
+  __shared__ bf16x8 W3r[10][64], W3l[10][64];  // rows (d,h) of block blk (row order of conv_bwd_kernel), K = x channel
+  extern __shared__ __attribute__((aligned(16))) char Ps[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  for (int f = wave; f < 10; f += 8) {
+    const int blk = f >> 1, ks = f & 1;
+    const int j = (l31 & 3) + 4 * (l31 >> 3), hr = (l31 >> 2) & 1;
+    const int d = 2 * blk + (j >> 3), h = 8 * hr + (j & 7);
+    float v[8];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) y[h] = 0.f;
-#pragma unroll 1
-    for (int d = 0; d < 9; ++d) {
-      const int qy = py + d / 3 - 1, qx = px + d % 3 - 1;
-      if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
-      const size_t q = ((size_t)b * H + qy) * W + qx;
-      float xv[XC], g[MAXH];
-      load_x32(x + q * XC, xv);
-      load_g16(G + q * MAXH, g);
+    for (int e = 0; e < 8; ++e) v[e] = (d < 9 && h < NH) ? W3[((size_t)h * 9 + d) * XC + ks * 16 + half * 8 + e] : 0.f;
+    frag8_split(v, W3r[f][lane], W3l[f][lane]);
+  }
+  const int tiles_x = (W + CF_TW - 1) / CF_TW, tiles_y = (H + CF_TH - 1) / CF_TH;
+  const int nblocks = B * tiles_y * tiles_x;
+  const int pix = threadIdx.x & 127, hq = threadIdx.x >> 7;  // phase 2: four threads per output pixel, four heads each
+  const int oy = pix / CF_TW, ox = pix - oy * CF_TW;
+  float bias[4];
 #pragma unroll
-      for (int h = 0; h < MAXH; ++h) {
-        if (h < NH) {
-          const float4* w = (const float4*)(w3s + (h * 9 + d) * XC);
-          float a = 0.f;
+  for (int e = 0; e < 4; ++e) bias[e] = (hq * 4 + e < NH) ? b3[hq * 4 + e] : 0.f;
+
+  auto load_tile = [&](int bid, CfIn& in) __attribute__((always_inline)) {  // wave t owns MFMA pixel tile t of the halo region
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
+    const int r = wave * 32 + l31;
+    const int ry = r / CF_RW, rx = r - ry * CF_RW;
+    const int iy = ty * CF_TH - 1 + ry, ix = tx * CF_TW - 1 + rx;
+    const bool ok = bid < nblocks && wave < CF_NT && r < CF_NR && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const long long p = ok ? ((long long)b * H + iy) * W + ix : 0;
+    load_x_frags(x, p, ok, half, in.x0, in.x1);
+    in.g = ok ? *(const uint4*)(G + (size_t)p * MAXH + half * 8) : make_uint4(0, 0, 0, 0);
+  };
+  // one block per CU (the fp32 product tile fills LDS), so memory latency is covered by depth, not by occupancy:
+  // the rows of the next three tiles are in flight while the current one is computed
+  CfIn cur, n1, n2, n3;
+  load_tile(blockIdx.x, cur);
+  load_tile(blockIdx.x + gridDim.x, n1);
+  load_tile(blockIdx.x + 2 * gridDim.x, n2);
+  __syncthreads();  // W3r / W3l
+  for (int bid = blockIdx.x; bid < nblocks; bid += gridDim.x) {
+    load_tile(bid + 3 * gridDim.x, n3);
+    // ---- phase 1: gated products of the tile + halo
+    if (wave < CF_NT) {
+      const uint32_t gu[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w};
+      float g[8];
 #pragma unroll
-          for (int k = 0; k < XC / 4; ++k) {
-            const float4 ww = w[k];
-            a += ww.x * xv[4 * k] + ww.y * xv[4 * k + 1] + ww.z * xv[4 * k + 2] + ww.w * xv[4 * k + 3];
+      for (int e = 0; e < 8; ++e) g[e] = __uint_as_float((e & 1) ? (gu[e >> 1] & 0xffff0000u) : (gu[e >> 1] << 16));
+      char* prow = Ps + (size_t)(wave * 32 + l31) * CF_PS + half * 32;
+      int tl = lane;  // opaque per iteration: the operand-table reads stay inside the loop
+      asm volatile("" : "+v"(tl));
+#pragma unroll
+      for (int blk = 0; blk < 5; ++blk) {
+        f32x16 T = mfma(W3r[2 * blk][tl], cur.x0.v, zero16());
+        T = mfma(W3r[2 * blk + 1][tl], cur.x1.v, T);
+        T = mfma(W3l[2 * blk][tl], cur.x0.v, T);
+        T = mfma(W3l[2 * blk + 1][tl], cur.x1.v, T);
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+          const int d = 2 * blk + dd;
+          if (d < 9) {
+            *(float4*)(prow + d * 64) = make_float4(g[0] * T[8 * dd], g[1] * T[8 * dd + 1], g[2] * T[8 * dd + 2], g[3] * T[8 * dd + 3]);
+            *(float4*)(prow + d * 64 + 16) =
+                make_float4(g[4] * T[8 * dd + 4], g[5] * T[8 * dd + 5], g[6] * T[8 * dd + 6], g[7] * T[8 * dd + 7]);
           }
-          y[h] += a * g[h];
         }
       }
     }
-    const size_t plane = (size_t)H * W, pix = (size_t)py * W + px;
+    __syncthreads();
+    // ---- phase 2: sum of the nine shifted entries, tanh, NCHW store
+    {
+      const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
+      const int py = ty * CF_TH + oy, px = tx * CF_TW + ox;
+      if (py < H && px < W) {
+        float y0 = bias[0], y1 = bias[1], y2 = bias[2], y3 = bias[3];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h)
-      if (h < NH) out[((size_t)b * NH + h) * plane + pix] = tanhf(y[h] + b3[h]);
+        for (int d = 0; d < 9; ++d) {
+          const float4 a = *(const float4*)(Ps + (size_t)((oy + d / 3) * CF_RW + ox + d % 3) * CF_PS + d * 64 + hq * 16);
+          y0 += a.x, y1 += a.y, y2 += a.z, y3 += a.w;
+        }
+        const size_t plane = (size_t)H * W;
+        float* o = out + ((size_t)b * NH + hq * 4) * plane + (size_t)py * W + px;
+        if (hq * 4 < NH) o[0] = fast_tanh(y0);
+        if (hq * 4 + 1 < NH) o[plane] = fast_tanh(y1);
+        if (hq * 4 + 2 < NH) o[2 * plane] = fast_tanh(y2);
+        if (hq * 4 + 3 < NH) o[3 * plane] = fast_tanh(y3);
+      }
+    }
+    __syncthreads();  // the products are consumed: the next tile may overwrite them
+    cur = n1, n1 = n2, n2 = n3;
   }
 }
 
@@ -926,8 +997,16 @@ MVIT_API int mvit_heads_gate_fwd(const void* x, const float* W1, const float* b1
 MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, const float* b3, float* out, int B, int H,
                                  int W, int NH, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (B <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
-  hipLaunchKernelGGL(conv_fwd_kernel, dim3(nblk((long long)B * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+  if (B <= 0 || H <= 0 || W <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute((const void*)conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_LDS) != hipSuccess)
+      return MVIT_EINVAL;
+    raised = true;
+  }
+  const long long blocks = (long long)B * ((H + CF_TH - 1) / CF_TH) * ((W + CF_TW - 1) / CF_TW);
+  if (blocks >= (1ll << 30)) return MVIT_EINVAL;
+  hipLaunchKernelGGL(conv_fwd_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(512), CF_LDS, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)G, W3, b3, out, B, H, W, NH);
   return MVIT_LAUNCH_CHECK();
 }
