@@ -5,8 +5,9 @@
 A step = one ModelModule.training_step on one synthetic minibatch per rank: HIP generator forward (H-Optimus-0 ViT-g/14
 encoder with LoRA + ViTMatte decoder, bf16 MFMA / f32 accumulate), fused WeightedMSE, HIP backward, gradient
 all-reduce (RCCL) when N>1, global-norm clip + Adam.  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the dense 256x128 MFMA GEMM
-with the plain store epilogue; algorithmic flops / HIP-event durations recorded live during the timed steps) and
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the instantiation with the
+largest share of the step in profiles/r01_kernel_stats_final.txt: the 4-wave 256x128 MFMA GEMM with the plain store
+epilogue, which runs the K >= 4096 dgrad GEMMs; algorithmic flops / HIP-event durations recorded live during the timed steps) and
 `cpu_baseline` (the CPU oracle = port of the reference arithmetic, timed on this host's cores on a bounded sample).
 """
 import argparse
@@ -202,7 +203,7 @@ def main():
     if rank == 0:
         if probe["n"]:
             ach = probe["flops"] / (probe["ms"] * 1e-3)
-            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE>",
+            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,2,2,DENSE,STORE>",
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16, 4), "traffic": pmc_traffic(), "launches": probe["n"],
                                "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
@@ -222,7 +223,7 @@ def pmc_traffic():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             k = json.load(f)["kernels"]
         for name, v in k.items():
-            if "gemm_kernel<256, 128, 4, 2, 0, 0>" in name:
+            if "gemm_kernel<256, 128, 2, 2, 0, 0>" in name:
                 return round(v["hbm_bytes_per_launch_corrected"])
     except Exception:  # noqa: BLE001
         pass
