@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--encoder", default="hoptimus0")
+    ap.add_argument("--metrics", type=int, default=0, help="train mode: also run the per-step PSNR/SSIM state update of the "
+                    "reference (models.py:140-143); the headline number is taken with it off (SURVEY.md section 6)")
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
     a = ap.parse_args()
 
@@ -125,6 +127,7 @@ def main():
     mod = ModelModule(model, None, 2e-4 * a.batch ** 0.5, 0., WeightedMSELoss(50.0, weights)).to(dev)
     mod.total_iters = 100000
     mod.nan_check_every = 10 ** 9   # the guard's host copy is exercised in tests, not inside the timed region
+    mod.update_pix_metrics = bool(a.metrics)
     if world > 1 or force_ddp:
         sync = DataParallelSync(eng, force=force_ddp)
         sync.broadcast_parameters(0)
@@ -184,7 +187,7 @@ def main():
         "config": {"workload": f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) {a.mode} step, "
                                f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} " +
                                ("(SURVEY.md 8f row 4)" if a.mode == "embed" else f"(BASELINE.json configs[{cfg_idx}])"),
-                   "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}"},
+                   "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}", "pix_metrics": bool(a.metrics)},
     }
     if a.mode == "infer":
         # p50 latency of one batch, measured after the throughput window with a sync per batch

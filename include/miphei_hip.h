@@ -194,6 +194,17 @@ MVIT_API int mvit_heads_gate_bwd(const void* x, const void* G, const float* dG, 
                                  float* dW2, float* db2, void* dF /*bf16 [M,32]*/, long long M, int NH, double count,
                                  mvit_stream_t stream);
 
+/* ---------------------------------------------------------------- per-step image metrics */
+/* torchmetrics 1.6.2 PeakSignalNoiseRatio / StructuralSimilarityIndexMeasure state updates with data_range=(lo, hi), as
+ * called at src/models.py:140-143 (train) and in evaluation_step: pred / target f32 NCHW;
+ * state[0] += sum (clamp(p)-clamp(t))^2, state[1] += numel, state[2] += sum_b SSIM_b (11x11 Gaussian window, sigma 1.5,
+ * windows fully inside the image), state[3] += B.  scratch: slotted partial sums (mvit_pix_metrics_scratch_bytes(B) bytes),
+ * zero before the first call, left zero by every call. */
+MVIT_API long long mvit_pix_metrics_scratch_bytes(int B);
+MVIT_API int mvit_pix_metrics_update(const float* pred, const float* target, double* state /*[4]*/, double* scratch,
+                                     long long scratch_bytes, int B, int C, int H, int W, float lo, float hi,
+                                     mvit_stream_t stream);
+
 /* ---------------------------------------------------------------- loss / optimiser */
 /* WeightedMSELoss (src/loss.py:47-57): loss_acc += sum_c w_c sum (p-t)^2 (caller multiplies by lambda/(C*B*HW));
  * dY = 2*lambda/(C*B*HW) * w_c * (p-t).  pred/target/dY are NCHW f32. */

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mvit_heads_conv_bwd": [vp, vp, vp, vp, vp, vp, ll, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_heads_gate_bwd_scratch_bytes": [],
     "mvit_heads_gate_bwd": [vp] * 14 + [ll] + [vp] * 6 + [ll, ci, cd, vp],
+    "mvit_pix_metrics_scratch_bytes": [ci],
+    "mvit_pix_metrics_update": [vp, vp, vp, vp, ll, ci, ci, ci, ci, cf, cf, vp],
     "mvit_wmse_fwd_bwd": [vp, vp, vp, vp, vp, ci, ci, ll, cf, vp],
     "mvit_sqnorm": [vp, vp, ll, vp],
     "mvit_u8_nhwc_to_f32_nchw": [vp, vp, vp, vp, ci, ci, ll, vp],

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .loss import WeightedMSELoss
+from .metrics import PixMetrics
 from .utils import pix2pix_lr_scheduler
 
 try:  # pragma: no cover - not installed in the build container
@@ -54,6 +55,11 @@ class ModelModule(_Base):
         self._pending_loss = None
         self.grad_sync = None  # set by trainer.DataParallelSync for multi-GPU runs
         self.last_loss = None
+        # PSNR / SSIM collections of the reference (models.py:35-52), device-resident state, updated after every step
+        self.train_pix_metrics = PixMetrics((-0.9, 0.9))
+        self.val_pix_metrics = self.train_pix_metrics.clone(prefix="val_")
+        self.test_pix_metrics = self.train_pix_metrics.clone(prefix="test_")
+        self.update_pix_metrics = True
 
     # ------------------------------------------------------------------ inference
     def forward(self, inputs):
@@ -108,7 +114,15 @@ class ModelModule(_Base):
         self.global_step_ += 1
         self.last_loss = loss
         self._nan_guard(loss)
+        if self.update_pix_metrics:  # reference models.py:140-143 (the clip to [-0.9, 0.9] is the metrics' own clamp)
+            self.train_pix_metrics.update(out, y)
         return loss
+
+    def on_train_epoch_end(self):
+        """reference models.py:207-213: compute, hand to the logger, reset"""
+        vals = self.train_pix_metrics.compute()
+        self.train_pix_metrics.reset()
+        return vals
 
     def _nan_guard(self, loss):
         """Asynchronous form of the reference's NaN guard: a NaN/Inf anywhere in the generator output makes the loss
@@ -126,11 +140,17 @@ class ModelModule(_Base):
             ev.record()
             self._pending_loss = (ev, host)
 
-    def validation_step(self, batch, batch_idx=0):
+    def _evaluation_step(self, batch, metrics):
         self.generator.eval()
         with torch.no_grad():
             out = self.generator(batch["image"])
-            return self.loss_reconstruct(batch["target"].to(out.device), out)
+            y = batch["target"].to(out.device)
+            if self.update_pix_metrics:  # reference evaluation_step, models.py:294-296
+                metrics.update(out, y)
+            return self.loss_reconstruct(y, out)
+
+    def validation_step(self, batch, batch_idx=0):
+        return self._evaluation_step(batch, self.val_pix_metrics)
 
     def test_step(self, batch, batch_idx=0):
-        return self.validation_step(batch, batch_idx)
+        return self._evaluation_step(batch, self.test_pix_metrics)

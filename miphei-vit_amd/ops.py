@@ -268,6 +268,15 @@ def heads_gate_bwd(x, G, dG, dXc, W1, b1, scale, shift, mean, rstd, gamma, W2, m
           _p(dbeta), _p(dW2), _p(db2), _p(dF), M, NH, float(M))
 
 
+def pix_metrics_update(pred, target, state, scratch, B, C, H, W, lo, hi):
+    assert pred.dtype == torch.float32 and target.dtype == torch.float32 and state.dtype == torch.float64
+    _call("mvit_pix_metrics_update", _p(pred), _p(target), _p(state), _p(scratch), scratch.numel() * 8, B, C, H, W, lo, hi)
+
+
+def pix_metrics_scratch_doubles(B):
+    return int(L.lib().mvit_pix_metrics_scratch_bytes(B)) // 8
+
+
 def wmse_fwd_bwd(pred, target, w, loss_acc, dY, lambda_factor):
     B, Cc, H, W = pred.shape
     _call("mvit_wmse_fwd_bwd", _p(pred), _p(target), _p(w), _p(loss_acc), _p(dY), B, Cc, H * W, lambda_factor)
