@@ -96,7 +96,7 @@ MVIT_API int mvit_wmse_fwd_bwd(const float* pred, const float* target, const flo
   if (B <= 0 || C <= 0 || HW <= 0) return MVIT_EINVAL;
   // loss = lambda/(C*B*HW) * sum_c w_c sum (p-t)^2  (caller scales loss_acc); dY = 2*lambda/(C*B*HW) * w_c * (p-t)
   const float coef = 2.f * lambda_factor / ((float)C * (float)B * (float)HW);
-  hipLaunchKernelGGL(wmse_kernel, dim3(nblk(HW, 1024 * 4, 64), B * C), dim3(256), 0, (hipStream_t)stream, pred, target, w,
+  hipLaunchKernelGGL(wmse_kernel, dim3(nblk(HW, 1024 * 16, 16), B * C), dim3(256), 0, (hipStream_t)stream, pred, target, w,
                      loss_acc, dY, C, HW, coef);
   return MVIT_LAUNCH_CHECK();
 }
@@ -104,7 +104,7 @@ MVIT_API int mvit_wmse_fwd_bwd(const float* pred, const float* target, const flo
 MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (n <= 0) return MVIT_EINVAL;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk(n, 1024 * 4, 1024)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk(n, 1024 * 16, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
   return MVIT_LAUNCH_CHECK();
 }
 
