@@ -227,6 +227,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * RPI * 128), 16, off, soff, 0, 0);
     }
   };
+  // pieces [p0, p1) of the same tile (piece j < A_CH is an A chunk, the rest are B chunks): lets the one-wave-per-SIMD
+  // loop spread the DMA issue of a K tile over its MFMA sub-steps
+  auto issue_pieces_fast = [&](int t, int buf, auto p0_tag, auto p1_tag) __attribute__((always_inline)) {
+    constexpr int P0 = decltype(p0_tag)::value, P1 = decltype(p1_tag)::value;
+    char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
+    char* b = a + A_BYTES;
+    const int soff = t * (BK * 2);
+    const unsigned sa = (unsigned)(RPI * 2) * (unsigned)p.lda, sb = (unsigned)(RPI * 2) * (unsigned)p.ldb;
+#pragma unroll
+    for (int j = P0; j < P1; ++j) {
+      if (j < A_CH) {
+        unsigned off = (validA >> j) & 1 ? baseA + (unsigned)j * sa : OOB;
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, soff, 0, 0);
+      } else {
+        const int jb = j - A_CH;
+        unsigned off = (validB >> jb) & 1 ? baseB + (unsigned)jb * sb : OOB;
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + jb * RPI * 128), 16, off, soff, 0, 0);
+      }
+    }
+  };
   auto issue_tile = [&](int t, int buf) __attribute__((always_inline)) {
     if (AMODE == MVIT_A_DENSE && (t + 1) * BK <= p.K)
       issue_tile_fast(t, buf, 0);
@@ -302,22 +324,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       };
+      // The refill of a step goes to the buffer consumed in the PREVIOUS step (free since that step's hand-over), so its
+      // DMA pieces can be spread over the first three MFMA sub-steps instead of bursting after the hand-over; the
+      // hand-over (wait for tile t+1, barrier, first fragments of tile t+1) sits in front of the last sub-step.
+      // `tight` steps: the refill is a full dense tile (straight-line DMA code), the whole step is two scheduling
+      // regions and the instruction mix is pinned with sched_group_barrier.
       wait_tile(t_begin);
       __builtin_amdgcn_s_barrier();
-      if (t_begin + NSTAGE - 1 < t_end) issue_tile(t_begin + NSTAGE - 1, ib);
       load_frags(smem + cb * BUF_BYTES, smem + cb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
-      // `tight` K steps: the refill issued in the step is a full dense tile (straight-line DMA code), so the whole
-      // step is two scheduling regions and the instruction mix is pinned with sched_group_barrier:
-      // one fragment read per two MFMAs in the first three sub-steps, DMA issue + first reads of the next tile
-      // spread over the MFMAs of the last one.
+      constexpr int PG = (LPT + 2) / 3;  // DMA pieces per sub-step
       auto kstep = [&](int t, auto tight_tag) __attribute__((always_inline)) {
         constexpr bool tight = decltype(tight_tag)::value;
         const char* a = smem + cb * BUF_BYTES;
         const char* b = a + A_BYTES;
+        if constexpr (tight) {
+          issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, 0>{}, std::integral_constant<int, PG>{});
+        } else {
+          if (t + NSTAGE - 1 < t_end) issue_tile(t + NSTAGE - 1, ib);
+        }
         load_frags(a, b, 1, fa[1], fb[1]);
         mma(fa[0], fb[0]);
+        if constexpr (tight)
+          issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, PG>{}, std::integral_constant<int, (2 * PG < LPT ? 2 * PG : LPT)>{});
         load_frags(a, b, 2, fa[0], fb[0]);
         mma(fa[1], fb[1]);
+        if constexpr (tight)
+          issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, (2 * PG < LPT ? 2 * PG : LPT)>{}, std::integral_constant<int, LPT>{});
         load_frags(a, b, 3, fa[1], fb[1]);
         mma(fa[0], fb[0]);
         if constexpr (tight) {
@@ -325,6 +357,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           for (int g = 0; g < 3 * (TM + TN); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // 1 LDS read
             __builtin_amdgcn_sched_group_barrier(0x008, (TM * TN) / (TM + TN), 0);  // MFMAs
+            if (g * LPT / (3 * (TM + TN)) != (g + 1) * LPT / (3 * (TM + TN)))
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    // 1 DMA piece
           }
         }
         const int nb = cb + 1 == NSTAGE ? 0 : cb + 1;
@@ -339,11 +373,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
             wait_tile(t + 1);
           }
           __builtin_amdgcn_s_barrier();
-          if constexpr (tight) {
-            issue_tile_fast(t + NSTAGE, cb, 0);
-          } else {
-            if (t + NSTAGE < t_end) issue_tile(t + NSTAGE, cb);
-          }
           load_frags(smem + nb * BUF_BYTES, smem + nb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
         }
         mma(fa[1], fb[1]);
@@ -351,16 +380,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #pragma unroll
           for (int g = 0; g < TM + TN; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);            // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, LPT / (TM + TN), 1);  // DMA pieces
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);            // LDS read
             __builtin_amdgcn_sched_group_barrier(0x008, (TM * TN) / (TM + TN) - 1, 1);
           }
         }
         cb = nb;
+        ib = ib + 1 == NSTAGE ? 0 : ib + 1;
       };
       int t = t_begin;
       if (AMODE == MVIT_A_DENSE) {
-        const int t_tight = min(t_end, p.K / BK) - NSTAGE;
+        const int t_tight = min(t_end, p.K / BK) - (NSTAGE - 1);
         for (; t < t_tight; ++t) kstep(t, std::true_type{});
       }
       for (; t < t_end; ++t) kstep(t, std::false_type{});
