@@ -55,7 +55,7 @@ static int select_variant(const mvit_gemm_args& a) {
   static const int w4 = [] { const char* e = getenv("MVIT_GEMM_W4"); return e ? atoi(e) : 0; }();
   auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
   if (huge) return (w4 & 1) ? id(256, 256, 2, 2) : id(256, 256, 2, 4);
-  if (big && dense && (a.N % 128 == 0) && a.epi != MVIT_EPI_SWIGLU && ((w4 & 2) || (!(w4 & 4) && a.K >= 4096 && a.ksplit <= 1)))
+  if (big && dense && (a.N % 128 == 0) && (a.epi != MVIT_EPI_SWIGLU || (w4 & 16)) && ((w4 & 2) || (!(w4 & 4) && a.K >= 4096 && a.ksplit <= 1)))
     return id(256, 128, 2, 2);
   if (a.epi == MVIT_EPI_SWIGLU) {
     if ((a.N % 128) || !dense) return -1;
