@@ -194,5 +194,9 @@ extern "C" MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_st
     return MVIT_EINVAL;
   }
   hipStream_t s = (hipStream_t)stream;
-  return a.J <= 32 ? launch<128, 32>(a, s) : launch<64, 128>(a, s);
+  // tile choice: narrow outputs keep JT at the padded J (a 128-wide tile on J = 64 would spend half its DMA and MFMA work
+  // on zero columns); tall outputs take 128 rows (fewer operand bytes per flop); the LoRA products (I = 16) stay on 64 rows
+  if (a.J <= 32) return launch<128, 32>(a, s);
+  if (a.J <= 64) return a.I >= 128 ? launch<128, 64>(a, s) : launch<64, 128>(a, s);
+  return a.I >= 512 ? launch<128, 128>(a, s) : launch<64, 128>(a, s);
 }
