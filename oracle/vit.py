@@ -91,17 +91,24 @@ def vit_state_shapes(cfg: ViTConfig, img: int, prefix: str = "encoder.vit.", lor
     return {prefix + k: v for k, v in s.items()}
 
 
+def lora_qkv(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor, Aq: torch.Tensor, Bq: torch.Tensor, Av: torch.Tensor,
+             Bv: torch.Tensor, alpha: float) -> torch.Tensor:
+    """QkvWithLoRA.forward (lora.py:29-33): fused qkv projection, alpha*(h A B) added on the q (first D) and v (last D) columns."""
+    D = h.shape[-1]
+    qkv = F.linear(h, w, b)
+    dq = alpha * (h @ Aq @ Bq)
+    dv = alpha * (h @ Av @ Bv)
+    return torch.cat([qkv[..., :D] + dq, qkv[..., D : 2 * D], qkv[..., 2 * D :] + dv], dim=-1)
+
+
 def vit_block(p: dict, pre: str, x: torch.Tensor, cfg: ViTConfig, lora: bool) -> torch.Tensor:
     """One timm Block: x + ls1*attn(norm1 x); x + ls2*mlp(norm2 x)  (App. A)."""
     B, N, D = x.shape
     H, Dh = cfg.heads, D // cfg.heads
     h = F.layer_norm(x, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps)
     if lora:
-        qkv = F.linear(h, p[pre + "attn.qkv.qkv.weight"], p[pre + "attn.qkv.qkv.bias"])
-        # lora.py:29-33 -- in-place add on the q (first D) and v (last D) columns
-        dq = cfg.lora_alpha * (h @ p[pre + "attn.qkv.lora_q.A"] @ p[pre + "attn.qkv.lora_q.B"])
-        dv = cfg.lora_alpha * (h @ p[pre + "attn.qkv.lora_v.A"] @ p[pre + "attn.qkv.lora_v.B"])
-        qkv = torch.cat([qkv[..., :D] + dq, qkv[..., D : 2 * D], qkv[..., 2 * D :] + dv], dim=-1)
+        qkv = lora_qkv(h, p[pre + "attn.qkv.qkv.weight"], p[pre + "attn.qkv.qkv.bias"], p[pre + "attn.qkv.lora_q.A"],
+                       p[pre + "attn.qkv.lora_q.B"], p[pre + "attn.qkv.lora_v.A"], p[pre + "attn.qkv.lora_v.B"], cfg.lora_alpha)
     else:
         qkv = F.linear(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
     qkv = qkv.reshape(B, N, 3, H, Dh).permute(2, 0, 3, 1, 4)
