@@ -80,6 +80,14 @@ def _bn(p, pre, x, training, new_stats):
     return xh * w[None, :, None, None] + b[None, :, None, None]
 
 
+def segmentation_head(p: dict, pre: str, f: torch.Tensor, training: bool, new_stats: dict | None = None) -> torch.Tensor:
+    """SegmentationHead(32, 1, use_attention=True, Tanh) (unet.py:407-438): y = tanh(conv3x3(f * sigmoid(psi(f))))."""
+    t = F.conv2d(f, p[pre + "0.psi.0.weight"], p[pre + "0.psi.0.bias"])
+    t = F.relu(_bn(p, pre + "0.psi.1.", t, training, new_stats))
+    g = torch.sigmoid(F.conv2d(t, p[pre + "0.psi.3.weight"], p[pre + "0.psi.3.bias"]))
+    return torch.tanh(F.conv2d(f * g, p[pre + "1.weight"], p[pre + "1.bias"], padding=1))
+
+
 def decoder_forward(p: dict, features: torch.Tensor, images: torch.Tensor, nc_out: int, training: bool = False,
                     prefix: str = "decoder.", new_stats: dict | None = None, return_mids: bool = False):
     """Detail_Capture.forward (mipheivit.py:207-220) with Tanh heads."""
@@ -102,11 +110,6 @@ def decoder_forward(p: dict, features: torch.Tensor, images: torch.Tensor, nc_ou
         mids[f"F{i}"] = f
     outs = []
     for h in range(nc_out):
-        pre = f"{prefix}segmentation_head_{h}."
-        t = F.conv2d(f, p[pre + "0.psi.0.weight"], p[pre + "0.psi.0.bias"])
-        t = F.relu(_bn(p, pre + "0.psi.1.", t, training, new_stats))
-        g = torch.sigmoid(F.conv2d(t, p[pre + "0.psi.3.weight"], p[pre + "0.psi.3.bias"]))
-        y = F.conv2d(f * g, p[pre + "1.weight"], p[pre + "1.bias"], padding=1)
-        outs.append(torch.tanh(y))
+        outs.append(segmentation_head(p, f"{prefix}segmentation_head_{h}.", f, training, new_stats))
     out = torch.cat(outs, dim=1)
     return (out, mids) if return_mids else out
