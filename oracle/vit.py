@@ -52,6 +52,9 @@ VIT_CONFIGS = {
     "tiny": ViTConfig(patch=16, dim=64, depth=2, heads=4, mlp="gelu", hidden=256, reg_tokens=4),
     # small SwiGLU/patch-14 config exercising every H-Optimus-0 code path
     "tiny_swiglu": ViTConfig(patch=14, dim=96, depth=2, heads=3, mlp="swiglu", hidden=512, reg_tokens=4),
+    # depth-4 variants for the UNETR baseline (ViTPyramidEncoder needs >= 4 blocks, unet.py:131-137)
+    "tiny4": ViTConfig(patch=16, dim=64, depth=4, heads=4, mlp="gelu", hidden=256, reg_tokens=4),
+    "tiny4_swiglu": ViTConfig(patch=14, dim=96, depth=4, heads=3, mlp="swiglu", hidden=512, reg_tokens=4),
 }
 
 
