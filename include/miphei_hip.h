@@ -161,6 +161,11 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
  * wk [Cout, 9*Cp] (forward), wd [Cp, 9*Cout] (dgrad, may be NULL); packed channel c = source channel (c+rot) mod Cin */
 MVIT_API int mvit_pack_conv3x3_weights(const float* W, void* wk, void* wd, int Cout, int Cin, int Cp, int rot,
                                        mvit_stream_t stream);
+/* ConvTranspose2d(k=2, s=2) output placement (src/generators/unet.py:304-372,490-498): the GEMM result packed[M, 4*C]
+ * (column (dy*2+dx)*C + c) <-> NHWC image [B, 2H, 2W] with row stride ld_img (a channel slice of a concat buffer).
+ * inverse = 0: packed -> image; 1: image gradient -> packed. */
+MVIT_API int mvit_pixel_shuffle2x(void* packed, void* img, int B, int H, int W, int C, long long ld_img, int inverse,
+                                  mvit_stream_t stream);
 MVIT_API int mvit_transpose_bf16(const void* src, void* dst, int R, int Cc, int ld_src, long long ld_dst,
                                  mvit_stream_t stream);
 

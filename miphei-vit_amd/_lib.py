@@ -61,6 +61,7 @@ SIGNATURES = {
     "mvit_bn_relu_bwd_reduce": [vp, ci, vp, vp, vp, vp, vp, vp, ll, ci, ci, vp],
     "mvit_bn_relu_bwd_apply": [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, cd, vp],
     "mvit_pack_conv3x3_weights": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "mvit_pixel_shuffle2x": [vp, vp, ci, ci, ci, ci, ll, ci, vp],
     "mvit_transpose_bf16": [vp, vp, ci, ci, ci, ll, vp],
     "mvit_heads_moments": [vp, vp, ll, ci, vp],
     "mvit_heads_bn_from_moments": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cf, cf, ci, vp],

@@ -284,6 +284,33 @@ __global__ __launch_bounds__(256) void pack_conv_w_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------ ConvTranspose2d(kernel 2, stride 2) pixel shuffle
+// The transposed convolution is a GEMM [B*H*W, Cin] x [4*Cout, Cin]^T whose column (dy*2+dx)*C + c belongs to output
+// pixel (2y+dy, 2x+dx), channel c (reference: nn.ConvTranspose2d in Deconv2DBlock / Decoder, src/generators/unet.py:304-372,
+// 490-498).  forward: packed [M, 4C] -> NHWC [B, 2H, 2W, ld_dst] (a channel slice of a concat buffer);
+// inverse: the adjoint gather of the output gradient back into the packed layout.
+__global__ __launch_bounds__(256) void pixel_shuffle2x_kernel(bf16_t* __restrict__ packed, bf16_t* __restrict__ img, int B, int H,
+                                                              int W, int C, long long ld_img, int inverse) {
+  const int c8n = C / 8;
+  const long long total = (long long)B * H * W * 4 * c8n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % c8n);
+    long long t = i / c8n;
+    const int q = (int)(t & 3);
+    const long long m = t >> 2;
+    const int x = (int)(m % W);
+    const long long t2 = m / W;
+    const int y = (int)(t2 % H), b = (int)(t2 / H);
+    const long long pix = ((long long)b * 2 * H + 2 * y + (q >> 1)) * (2 * W) + 2 * x + (q & 1);
+    uint4* ps = (uint4*)(packed + (size_t)m * 4 * C + (size_t)q * C + c8 * 8);
+    uint4* pi = (uint4*)(img + (size_t)pix * ld_img + c8 * 8);
+    if (inverse)
+      *ps = *pi;
+    else
+      *pi = *ps;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -368,6 +395,16 @@ MVIT_API int mvit_pack_conv3x3_weights(const float* W, void* wk, void* wd, int C
   const int total = Cout * Cp;
   hipLaunchKernelGGL(pack_conv_w_kernel, dim3(min((total + 255) / 256, 2048), wd ? 2 : 1), dim3(256), 0, (hipStream_t)stream, W,
                      (bf16_t*)wk, (bf16_t*)wd, Cout, Cin, Cp, rot);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_pixel_shuffle2x(void* packed, void* img, int B, int H, int W, int C, long long ld_img, int inverse,
+                                  mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (ld_img & 7) || ld_img < C) return MVIT_EINVAL;
+  const long long total = (long long)B * H * W * 4 * (C / 8);
+  hipLaunchKernelGGL(pixel_shuffle2x_kernel, dim3((unsigned)min((total + 255) / 256, (long long)8192)), dim3(256), 0,
+                     (hipStream_t)stream, (bf16_t*)packed, (bf16_t*)img, B, H, W, C, ld_img, inverse);
   return MVIT_LAUNCH_CHECK();
 }
 

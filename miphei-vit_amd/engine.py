@@ -423,7 +423,8 @@ class HipEngine:
         return w
 
     # ------------------------------------------------------------------ forward
-    def _encoder_fwd(self, w, x, train, pk):
+    def _encoder_fwd(self, w, x, train, pk, taps=None):
+        """taps: {block index: bf16 [M, D] buffer} receives the residual stream after that block (forward_intermediates)"""
         c, fz = self._config(), self._ensure_frozen()
         B, M, D = w.B, w.M, c.D
         P = c.grid * c.grid
@@ -452,6 +453,8 @@ class HipEngine:
             ops.gemm(w.h2, b.wfc1, w.g, bias=b.bfc1, aux=(w.u[l] if train else None),
                      epi=EPI_SWIGLU if c.swiglu else EPI_GELU)
             ops.gemm(w.g, b.wfc2, xout, bias=b.bfc2, gamma=b.ls2, aux=xmid, epi=EPI_RESID, flags=OUT_F32)
+            if taps is not None and l in taps:
+                ops.cast_bf16(xout, taps[l])
         xf = w.x_in[c.L] if train else w.x_in[0]
         ops.layernorm_fwd(xf, fz.nw, fz.nb, w.tok, c.eps)
         return w.tok

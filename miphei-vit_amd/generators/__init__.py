@@ -16,7 +16,7 @@ def _cfg_get(cfg, path, default=None):
 
 
 def get_generator(model_name, img_size, nc_in, nc_out, cfg):
-    """Only the MIPHEI-ViT branch (``myvitmatte*``) is in scope; the baselines (smp_unet, unet, hemit) are not."""
+    """The MIPHEI-ViT branch (``myvitmatte*``) and the UNETR baseline on the registry ViTs (``unet*``); smp_unet / hemit are not."""
     if model_name.startswith("myvitmatte"):
         if nc_in != 3:
             raise ValueError("MIPHEI-ViT takes 3-channel H&E tiles")
@@ -24,4 +24,16 @@ def get_generator(model_name, img_size, nc_in, nc_out, cfg):
         pretrained = _cfg_get(cfg, "model.encoder.pretrained", True)
         return get_vitmatte(_cfg_get(cfg, "model.encoder.encoder_name"), img_size, nc_out, use_lora=True,
                             ckpt_path=ckpt_path, pretrained=pretrained)
-    raise NotImplementedError(f"generator '{model_name}' is outside the MI355X hot path (only 'myvitmatte*')")
+    if model_name.startswith("unet"):
+        # UNETR baseline (reference src/generators/__init__.py:25-41); forward only on this path so far
+        if _cfg_get(cfg, "train.foreground_head", False):
+            raise NotImplementedError
+        from .unet import Unet
+        gen = Unet(img_size=img_size, encoder_name=_cfg_get(cfg, "model.encoder.encoder_name"),
+                   encoder_weights=_cfg_get(cfg, "model.encoder.encoder_weights"), decoder_out_channels=32,
+                   head_use_attention=True, use_lora="lora" in model_name, classes=nc_out,
+                   drop_rate=_cfg_get(cfg, "model.dropout", 0.0) or 0.0, pretrained=_cfg_get(cfg, "model.encoder.pretrained", True))
+        if "frozen" in model_name:
+            gen.freeze_encoder()
+        return gen
+    raise NotImplementedError(f"generator '{model_name}' is outside the MI355X hot path ('myvitmatte*', 'unet*')")

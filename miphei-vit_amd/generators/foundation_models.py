@@ -187,8 +187,21 @@ def tiny_swiglu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., g
                   mlp="swiglu", hidden=512, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
 
 
+def tiny4_gelu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
+    """depth-4 variant of `tiny` (the UNETR baseline needs >= 4 blocks)"""
+    return _build(img_size, False, ckpt_path, "tiny4", patch_size=16, embed_dim=64, depth=4, num_heads=4, mlp="gelu",
+                  hidden=256, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+
+
+def tiny4_swiglu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
+    return _build(img_size, False, ckpt_path, "tiny4_swiglu", patch_size=14, embed_dim=96, depth=4, num_heads=3,
+                  mlp="swiglu", hidden=512, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+
+
 FOUNDATION_MODEL_REGISTRY = {
     "hoptimus0": hoptimus0,
     "tiny": tiny_gelu,
     "tiny_swiglu": tiny_swiglu,
+    "tiny4": tiny4_gelu,
+    "tiny4_swiglu": tiny4_swiglu,
 }

@@ -226,6 +226,10 @@ def pack_conv3x3_weights(W, wk, wd, rot=0):
     _call("mvit_pack_conv3x3_weights", _p(W), _p(wk), _p(wd), cout, cin, cp, rot)
 
 
+def pixel_shuffle2x(packed, img, B, H, W, C_, ld_img, inverse=False):
+    _call("mvit_pixel_shuffle2x", _p(packed), _p(img), B, H, W, C_, ld_img, int(inverse))
+
+
 def transpose_bf16(src, dst, R, Cc, ld_src, ld_dst):
     _call("mvit_transpose_bf16", _p(src), _p(dst), R, Cc, ld_src, ld_dst)
 

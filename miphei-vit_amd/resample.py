@@ -47,7 +47,16 @@ def _identity(n_in: int, n_out: int) -> np.ndarray:
     return np.eye(n_in, dtype=np.float64)
 
 
-_DENSE = {"bilinear": _dense_bilinear, "bicubic": _dense_bicubic, "identity": _identity}
+def _dense_nearest(n_in: int, n_out: int) -> np.ndarray:
+    """nn.Upsample(scale_factor=n_out/n_in, mode='nearest'): src = min(floor(dst * n_in / n_out), n_in - 1)"""
+    R = np.zeros((n_out, n_in), dtype=np.float64)
+    scale = np.float32(1.0) / np.float32(n_out / n_in)       # torch keeps the user's scale_factor and inverts it in fp32
+    for o in range(n_out):
+        R[o, min(int(np.floor(np.float32(o) * scale)), n_in - 1)] = 1.0
+    return R
+
+
+_DENSE = {"bilinear": _dense_bilinear, "bicubic": _dense_bicubic, "identity": _identity, "nearest": _dense_nearest}
 
 
 @functools.lru_cache(maxsize=None)
