@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* _
                                                                  const float* __restrict__ shift,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  double* __restrict__ stats, long long M, int C, int nslots) {
-  __shared__ float red[2 * 256];
+  __shared__ float red[2 * 512];
   for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
   __syncthreads();
   const int cv = C >> 3;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __
                                                                 const double* __restrict__ stats, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, bf16_t* __restrict__ dx,
                                                                 long long M, int C, int nslots, double count) {
-  __shared__ float s1s[256], s2s[256];
+  __shared__ float s1s[512], s2s[512];
   for (int c = threadIdx.x; c < C; c += 256) {
     double a = 0., b = 0.;
     for (int k = 0; k < nslots; ++k) {
@@ -360,7 +360,7 @@ MVIT_API int mvit_bn_relu_bwd_reduce(const void* dy, int ld_dy, const void* x, c
                                      const float* mean, const float* rstd, double* stats, long long M, int C, int nslots,
                                      mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || C <= 0 || (C & 7) || C > 256 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
+  if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
   const int rpb = 256 / (C >> 3);
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk(M, rpb * 16, 2048)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, stats, M, C, nslots);
@@ -372,7 +372,7 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
                                     float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
                                     mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || C <= 0 || (C & 7) || C > 256 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
+  if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(nblk(M * (C >> 3), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta,
                      (bf16_t*)dx, M, C, nslots, count);

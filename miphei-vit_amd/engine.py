@@ -111,28 +111,29 @@ class HipEngine:
             return self._flat
         dev = self._require_gpu()
         c = self._config()
-        vit, dec = self.model.encoder.vit, self.model.decoder
+        vit, dec = self.model.encoder.vit, getattr(self.model, "decoder", None)
         groups = []  # (name, [params]) in flat order
         if c.lora:
             for blk in vit.blocks:
                 q = blk.attn.qkv
                 groups += [q.lora_q.A, q.lora_q.B, q.lora_v.A, q.lora_v.B]
         n_lora = sum(p.numel() for p in groups)
-        convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
-        for cv in convs:
-            groups += [cv.conv.weight, cv.bn.weight, cv.bn.bias]
-        heads = self._heads()
-        stacked = [("W1", lambda h: h[0].psi[0].weight), ("b1", lambda h: h[0].psi[0].bias),
-                   ("bnw", lambda h: h[0].psi[1].weight), ("bnb", lambda h: h[0].psi[1].bias),
-                   ("W2", lambda h: h[0].psi[3].weight), ("b2", lambda h: h[0].psi[3].bias),
-                   ("W3", lambda h: h[1].weight), ("b3", lambda h: h[1].bias)]
-        head_off = {}
-        off = sum(p.numel() for p in groups)
-        for name, get in stacked:
-            head_off[name] = off
-            for h in heads:
-                groups.append(get(h))
-                off += get(h).numel()
+        head_off, heads, convs = {}, [], []
+        if dec is not None:
+            convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
+            for cv in convs:
+                groups += [cv.conv.weight, cv.bn.weight, cv.bn.bias]
+            heads = self._heads()
+            stacked = [("W1", lambda h: h[0].psi[0].weight), ("b1", lambda h: h[0].psi[0].bias),
+                       ("bnw", lambda h: h[0].psi[1].weight), ("bnb", lambda h: h[0].psi[1].bias),
+                       ("W2", lambda h: h[0].psi[3].weight), ("b2", lambda h: h[0].psi[3].bias),
+                       ("W3", lambda h: h[1].weight), ("b3", lambda h: h[1].bias)]
+            off = sum(p.numel() for p in groups)
+            for name, get in stacked:
+                head_off[name] = off
+                for h in heads:
+                    groups.append(get(h))
+                    off += get(h).numel()
         for p in groups:
             if p.dtype != torch.float32:
                 raise RuntimeError("training needs fp32 master parameters (do not call .half()/.bfloat16() on a model "
@@ -156,7 +157,7 @@ class HipEngine:
             k = int(torch.tensor(shape).prod())
             return buf[head_off[name]:head_off[name] + k].view(shape)
 
-        for buf, pre in ((flat, ""), (gflat, "d")):
+        for buf, pre in (((flat, ""), (gflat, "d")) if dec is not None else ()):
             setattr(f, pre + "W1", hv(buf, "W1", (NH, HEAD_HID, HEAD_C)))
             setattr(f, pre + "b1", hv(buf, "b1", (NH * HEAD_HID,)))
             setattr(f, pre + "bnw", hv(buf, "bnw", (NH * HEAD_HID,)))
@@ -174,6 +175,10 @@ class HipEngine:
                 setattr(f, pre + "Av", reg[:, 2].view(c.L, c.D, c.rank))
                 setattr(f, pre + "Bv", reg[:, 3].view(c.L, c.rank, c.D))
             assert per * c.L == n_lora
+        if dec is None:   # encoder-only engine (UNETR baseline: its decoder parameters live in UnetrEngine)
+            f.convs = []
+            self._flat = f
+            return f
         # running statistics: heads stacked, all num_batches_tracked share one tensor
         bns = [cv.bn for cv in convs] + [h[0].psi[1] for h in heads]
         nbt = torch.stack([b.num_batches_tracked.to(dev) for b in bns]).contiguous()
@@ -348,7 +353,7 @@ class HipEngine:
         w.tok = e(M, D)
         if not c.dec:
             if train:
-                raise NotImplementedError("the encoder-only engine is inference-only")
+                self._alloc_encoder_bwd(w, c, e, z)
             self._ws[key] = w
             return w
         G = S // 16
@@ -410,17 +415,22 @@ class HipEngine:
                 ow.append(ow[-1] + s_)
             w.dWt = [w.wscr[ow[i]:ow[i + 1]].view(9 * cinp[i], chans[i]) for i in range(7)]
             w.dW3 = w.wscr[ow[7]:ow[8]].view(c.NH * 9, HEAD_C)
-            w.dtok = z(M, D)
-            w.dx = e(M, D, dt=torch.float32)
-            w.dy = e(M, D)
-            w.du = e(M, c.hidden)
-            w.dh = e(M, D)
-            w.do = e(M, D)
-            w.dqkv = e(M, 3 * D)
-            w.dsum = e(B, c.H, c.ntok, dt=torch.float32)
-            w.dt = e(M, 2 * c.rank) if c.lora else None
+            self._alloc_encoder_bwd(w, c, e, z)
         self._ws[key] = w
         return w
+
+    @staticmethod
+    def _alloc_encoder_bwd(w, c, e, z):
+        M, D, B = w.M, c.D, w.B
+        w.dtok = z(M, D)
+        w.dx = e(M, D, dt=torch.float32)
+        w.dy = e(M, D)
+        w.du = e(M, c.hidden)
+        w.dh = e(M, D)
+        w.do = e(M, D)
+        w.dqkv = e(M, 3 * D)
+        w.dsum = e(B, c.H, c.ntok, dt=torch.float32)
+        w.dt = e(M, 2 * c.rank) if c.lora else None
 
     # ------------------------------------------------------------------ forward
     def _encoder_fwd(self, w, x, train, pk, taps=None):
@@ -690,11 +700,23 @@ class HipEngine:
         if on_decoder_done is not None:
             on_decoder_done()
         # ---- encoder (LoRA gradients; frozen weights need dgrad only)
+        self._encoder_bwd(w, pk, fl, fz)
+        return fl.gflat
+
+    def _encoder_bwd(self, w, pk, fl, fz, from_tokens=True, inject=None):
+        """Backward of the ViT blocks.  from_tokens: start from the gradient of the final-norm tokens in w.dtok (MIPHEI-ViT);
+        otherwise the caller has put the gradient of the last block's output into w.dx (f32).  inject(l) is called when w.dx
+        holds the gradient of block l's output coming from later blocks and may add to it (forward_intermediates taps)."""
+        c = self._config()
+        B, D, M = w.B, c.D, w.M
         r_ = c.rank
         scale = c.Dh ** -0.5
         lsplit = max(1, min(512 // ((D + 127) // 128), (M + 255) // 256))
         last = fz.blocks[c.L - 1]
-        ops.layernorm_bwd(w.dtok, w.x_in[c.L], fz.nw, w.dx, last.ls2, w.dy, c.eps, accumulate=False)
+        if from_tokens:
+            ops.layernorm_bwd(w.dtok, w.x_in[c.L], fz.nw, w.dx, last.ls2, w.dy, c.eps, accumulate=False)
+        else:
+            ops.scale_cols_cast(w.dx, last.ls2, w.dy)
         for l in range(c.L - 1, -1, -1):
             b = fz.blocks[l]
             # MLP branch: dy = ls2 * dx
@@ -716,11 +738,12 @@ class HipEngine:
                         c2=fl.dAv[l], isplit=r_)
             if l > 0:
                 ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
+                if inject is not None:
+                    inject(l - 1)
                 ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)
         if c.alpha != 1.0:
             fl.dBq.mul_(c.alpha)
             fl.dBv.mul_(c.alpha)
-        return fl.gflat
 
     # ------------------------------------------------------------------ fused training step
     def loss_and_grad(self, out, target, marker_weights, lambda_factor):

@@ -76,3 +76,50 @@ def test_hip_unetr_forward_matches_reference(golden_dir, name):
     assert _rel(sd["decoder.decoder0_header.1.block.1.running_var"].cpu(), g["bn_rv_after"]) < 2e-2
     assert _rel(sd["decoder.decoder0_header.1.block.1.running_mean"].cpu(), g["bn_rm_after"]) < 2e-2
     assert int(sd["decoder.decoder0_header.1.block.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny4_gelu_p16_128", "tiny4_swiglu_p14_128"])
+def test_hip_unetr_backward_matches_oracle_autograd(golden_dir, name):
+    """loss.backward() through the UNETR autograd bridge vs torch autograd on the CPU oracle (same weights / inputs); yardstick as in
+    test_generator_gpu: per parameter no noisier than 1.25x the same arithmetic under bf16 autocast (floor 2 %)."""
+    from oracle import synth_batch, weighted_mse_loss
+    from oracle.model import orion_marker_weights
+    from oracle.unetr import unetr_forward
+    from miphei_vit_amd.generators.unet import Unet
+    g, cfg, p, img, nc, B, seed = _load(golden_dir, name)
+    model = Unet(img, str(g["cfg"]), use_lora=True, classes=nc, pretrained=False)
+    model.load_state_dict(p)
+    model = model.cuda().train()
+    x, y = synth_batch(seed, B, img, nc)
+    w = orion_marker_weights(16)[:nc]
+    out = model(x.cuda())
+    loss = weighted_mse_loss(y.cuda(), out, w.cuda())
+    loss.backward()
+    named = dict(model.named_parameters())
+    train_keys = [k for k, v in named.items() if v.requires_grad]
+    assert any("lora" in k for k in train_keys) and not any(k.endswith("attn.proj.weight") for k in train_keys)
+
+    def ref_grads(autocast):
+        q = {k: (v.clone().requires_grad_(True) if k in train_keys else v.clone()) for k, v in p.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            o = unetr_forward(q, x, cfg, nc, training=True)
+        l = weighted_mse_loss(y, o.float(), w)
+        l.backward()
+        return float(l), {k: q[k].grad for k in train_keys}
+
+    loss_ref, gref = ref_grads(False)
+    _, gac = ref_grads(True)
+    assert abs(float(loss) - loss_ref) < 2e-3 * abs(loss_ref)
+    gnorm = float(torch.cat([v.flatten().double() for v in gref.values() if v is not None]).norm())
+    bad = {}
+    for k in train_keys:
+        got, gr = named[k].grad, gref[k]
+        assert got is not None, k
+        if gr is None or float(gr.double().norm()) < 1e-5 * gnorm:       # conv biases in front of train-mode BatchNorm
+            assert float(got.double().norm()) < 1e-4 * gnorm, k
+            continue
+        e_hip, e_ac = _rel(got.cpu(), gr), _rel(gac[k], gr)
+        if e_hip > max(1.25 * e_ac, 0.02):
+            bad[k] = (round(e_hip, 4), round(e_ac, 4))
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12]
