@@ -97,8 +97,10 @@ class ModelModule(_Base):
     def training_step(self, batch, batch_idx=0):
         x, y = batch["image"], batch["target"]
         eng = getattr(self.generator, "_engine", None)
-        if eng is None or not isinstance(self.loss_reconstruct, WeightedMSELoss):
-            raise NotImplementedError("the fused step needs a MIPHEI-ViT generator and WeightedMSELoss")
+        if eng is None:
+            raise NotImplementedError("training_step needs a generator of this package (HIP engine)")
+        if not hasattr(eng, "loss_and_grad") or not isinstance(self.loss_reconstruct, WeightedMSELoss):
+            return self._training_step_autograd(x, y)
         self.generator.train()
         out = eng.forward(x, train=True)
         w = self.loss_reconstruct.marker_weights
@@ -117,6 +119,33 @@ class ModelModule(_Base):
         if self.update_pix_metrics:  # reference models.py:140-143 (the clip to [-0.9, 0.9] is the metrics' own clamp)
             self.train_pix_metrics.update(out, y)
         return loss
+
+    def _training_step_autograd(self, x, y):
+        """The reference's own sequence (models.py:87-143) for generators without the fused step (UNETR baseline): forward and
+        backward through the autograd bridge of the HIP engine, torch global-norm clip, torch Adam + LambdaLR."""
+        if self.grad_sync is not None:
+            raise NotImplementedError("multi-GPU gradient exchange is wired into the fused MIPHEI-ViT step only")
+        if getattr(self, "_opt", None) is None:
+            opts, scheds = self.configure_optimizers()
+            self._opt, self._sched = opts[0], scheds[0]["scheduler"]
+        self.generator.train()
+        dev = next(self.generator.parameters()).device
+        out = self.generator(x.to(dev))
+        y = y.to(out.device)
+        if hasattr(self.loss_reconstruct, "marker_weights") and self.loss_reconstruct.marker_weights.device != out.device:
+            self.loss_reconstruct.to(out.device)
+        loss = self.loss_reconstruct(y_true=y, y_pred=out)
+        self._opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in self.generator.parameters() if p.requires_grad], 1.0)
+        self._opt.step()
+        self._sched.step()
+        self.global_step_ += 1
+        self.last_loss = loss.detach()
+        self._nan_guard(self.last_loss)
+        if self.update_pix_metrics:
+            self.train_pix_metrics.update(out.detach(), y)
+        return self.last_loss
 
     def on_train_epoch_end(self):
         """reference models.py:207-213: compute, hand to the logger, reset"""
