@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--encoder", default="hoptimus0")
+    ap.add_argument("--generator", choices=["myvitmatte", "unet_lora"], default="myvitmatte",
+                    help="unet_lora = the UNETR baseline of the reference (SURVEY.md 8f row 4); single GPU, no hipGraph")
     ap.add_argument("--metrics", type=int, default=0, help="train mode: also run the per-step PSNR/SSIM state update of the "
                     "reference (models.py:140-143); the headline number is taken with it off (SURVEY.md section 6)")
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
@@ -120,10 +122,19 @@ def main():
             emb_model = FOUNDATION_MODEL_REGISTRY[a.encoder](a.img, pretrained=False, global_pool="token")
         synthetic_init_(emb_model, seed=0)
         emb_model = emb_model.eval().half()
+    unet = a.generator == "unet_lora"
+    if unet and (world > 1 or a.mode == "embed"):
+        raise SystemExit("--generator unet_lora: single-GPU train / infer modes only")
     with torch.device(dev):
-        model = get_vitmatte("tiny" if a.mode == "embed" else a.encoder, a.img, nc, use_lora=True, pretrained=False)
+        if unet:
+            from miphei_vit_amd.generators.unet import Unet
+            model = Unet(a.img, a.encoder, use_lora=True, classes=nc, pretrained=False)
+        else:
+            model = get_vitmatte("tiny" if a.mode == "embed" else a.encoder, a.img, nc, use_lora=True, pretrained=False)
     synthetic_init_(model, seed=0)
     eng = model._engine
+    if unet:
+        a.graph = 0
     mod = ModelModule(model, None, 2e-4 * a.batch ** 0.5, 0., WeightedMSELoss(50.0, weights)).to(dev)
     mod.total_iters = 100000
     mod.nan_check_every = 10 ** 9   # the guard's host copy is exercised in tests, not inside the timed region
@@ -150,6 +161,9 @@ def main():
         elif a.graph:
             x_static.copy_(x)      # device-to-device; the tile batch is already resident
             run_graph()
+        elif unet:
+            with torch.no_grad():
+                model(x)
         else:
             eng.forward(x, train=False, bn_train=False)
 
@@ -175,7 +189,7 @@ def main():
         dt = float(t)
     tiles = world * a.batch * a.steps
     value = tiles / dt
-    flops_tile = (FLOPS_TRAIN if a.mode == "train" else FLOPS_ENC if a.mode == "embed" else FLOPS_FWD).get(a.img)
+    flops_tile = None if unet else (FLOPS_TRAIN if a.mode == "train" else FLOPS_ENC if a.mode == "embed" else FLOPS_FWD).get(a.img)
 
     cfg_idx = (1 if a.img == 256 else 3) if a.mode == "train" else 4
     res = {
@@ -184,7 +198,8 @@ def main():
         "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) {a.mode} step, "
+        "config": {"workload": (f"UNETR baseline ({a.encoder} + LoRA r8, ViT pyramid + up-conv decoder, 16 heads) " if unet else
+                                f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) ") + f"{a.mode} step, "
                                f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} " +
                                ("(SURVEY.md 8f row 4)" if a.mode == "embed" else f"(BASELINE.json configs[{cfg_idx}])"),
                    "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}", "pix_metrics": bool(a.metrics)},
