@@ -209,10 +209,9 @@ class UnetrEngine:
     def forward(self, x):
         m = self.model
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters())
-        if not needs_grad:
+        if not needs_grad or not m.training:
+            # eval mode never records a graph (backward through eval-mode BatchNorm is not part of the training path)
             return self._forward(x, train=False).clone()
-        if not m.training:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the training path")
         params = [p for p in m.parameters() if p.requires_grad]
         return _UnetrFn.apply(self, x, *params)
 

@@ -176,3 +176,29 @@ def test_unetr_training_steps_track_oracle(golden_dir):
         cos = float((d_hip.double() * d_ref.double()).sum() / (d_hip.double().norm() * d_ref.double().norm()))
         assert cos > 0.8, (k, cos)
     assert _rel(sd["decoder.decoder0_header.1.block.1.running_var"].cpu(), q["decoder.decoder0_header.1.block.1.running_var"]) < 2e-2
+
+
+@pytest.mark.gpu
+def test_unetr_half_eval_and_errors(golden_dir):
+    """evaluation convention of the reference scripts (generator.eval().cuda().half() on half inputs) and the error surface"""
+    from oracle import synth_batch
+    from miphei_vit_amd.generators import get_generator
+    from miphei_vit_amd.generators.unet import Unet
+    g, cfg, p, img, nc, B, seed = _load(golden_dir, "tiny4_gelu_p16_128")
+    model = Unet(img, str(g["cfg"]), use_lora=True, classes=nc, pretrained=False)
+    model.load_state_dict(p)
+    model = model.eval().cuda().half()
+    x, _ = synth_batch(seed, B, img, nc)
+    with torch.no_grad():
+        out = model(x.cuda().half())
+    assert out.dtype == torch.float16
+    ref = torch.as_tensor(g["out_eval"])
+    assert float((((out.float().cpu() - ref) ** 2).sum(dim=(0, 2, 3)) / (ref ** 2).sum(dim=(0, 2, 3))).max()) < 2e-3
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, img * 2, img * 2, device="cuda").half())
+    conf = {"model": {"encoder": {"encoder_name": "tiny", "encoder_weights": None, "pretrained": False}, "dropout": 0.0},
+            "train": {"foreground_head": False}}
+    with pytest.raises(ValueError):                        # depth-2 ViT: "Vit Should have a depth higher than 3" (unet.py:137)
+        get_generator("unet_lora", 128, 3, 3, conf)
+    with pytest.raises(NotImplementedError):
+        Unet(128, "restnet50_lunit_swav", classes=3, pretrained=False)
