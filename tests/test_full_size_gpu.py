@@ -1,0 +1,45 @@
+"""Parity at BASELINE.json's full model size (configs[1]: H-Optimus-0 ViT-g/14 + LoRA + ViTMatte decoder, 256x256, 16 markers):
+the 1.14 B-parameter HIP path against the fp32 CPU oracle on one synthetic tile pair - outputs within the north-star tolerance
+(1e-3 relative MSE per channel) and the training loss / gradient norm of the 6.7 M trainable parameters."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hoptimus0_f256_forward_loss_gradnorm_vs_oracle():
+    import bench
+    from oracle import VIT_CONFIGS
+    from oracle.model import OracleTrainer, orion_marker_weights
+    from miphei_vit_amd.generators import get_vitmatte
+    from miphei_vit_amd.loss import WeightedMSELoss
+    nc, B, img = 16, 2, 256
+    dev = torch.device("cuda:0")
+    with torch.device(dev):
+        model = get_vitmatte("hoptimus0", img, nc, use_lora=True, pretrained=False)
+    bench.synthetic_init_(model, seed=3)
+    assert sum(p.numel() for p in model.parameters()) == 1_141_576_432           # SURVEY.md section 8 a1 [probe]
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 6_697_712
+    x, y = bench.synthetic_batch(77, B, img, nc, dev)
+    w = orion_marker_weights(nc)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    p = {k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()}
+    tr = OracleTrainer(p, VIT_CONFIGS["hoptimus0"], nc, batch_size=B, total_iters=1000, weights=w)
+    tr.p = p
+    out_ref, loss_ref, gref = tr.loss_and_grads(x.cpu(), y.cpu())
+    model.train()
+    out = model(x)
+    loss = WeightedMSELoss(50.0, w).to(dev)(y_true=y, y_pred=out)
+    loss.backward()
+    o = out.detach().float().cpu()
+    rel = ((o - out_ref) ** 2).sum(dim=(0, 2, 3)) / (out_ref ** 2).sum(dim=(0, 2, 3))
+    assert float(rel.max()) < 1e-3, rel
+    assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref))
+    named = dict(model.named_parameters())
+    gn_hip = torch.cat([named[k].grad.flatten().double().cpu() for k in gref]).norm()
+    gn_ref = torch.cat([g.flatten().double() for g in gref.values()]).norm()
+    assert abs(float(gn_hip) - float(gn_ref)) < 0.05 * float(gn_ref), (float(gn_hip), float(gn_ref))
+    # the shallow end of the backward pass (heads, last fusion block) is only a few bf16 roundings away from fp32
+    for k in ("decoder.segmentation_head_3.1.weight", "decoder.segmentation_head_0.0.psi.3.weight", "decoder.fusion_blks.3.conv.bn.weight"):
+        g1, g0 = named[k].grad.double().cpu(), gref[k].double()
+        assert float((g1 - g0).norm() / g0.norm()) < 0.05, k
