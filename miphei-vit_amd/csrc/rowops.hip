@@ -63,13 +63,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   const int nv = D >> 2;
   const float4* xr = (const float4*)(x + (size_t)row * D);
   const uint2* gr = (const uint2*)(dh + (size_t)row * D);
-  float4 v[LN_MAXV], g[LN_MAXV];
+  float4 v[LN_MAXV], g[LN_MAXV], o[LN_MAXV];
+  float4* dxr = (float4*)(dx + (size_t)row * D);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int idx = lane + 64 * i;
     if (idx < nv) {
       v[i] = xr[idx];
+      // the running gradient is fetched with the other operands: read after the reductions it would sit behind each store
+      // of the loop below (same array), one exposed HBM latency per element group
+      o[i] = accumulate ? dxr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
       const uint2 t = gr[idx];
       const float4 ww = ((const float4*)w)[idx];
@@ -102,7 +106,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
   c1 = wave_sum(c1) / D;
   c2 = wave_sum(c2) / D;
-  float4* dxr = (float4*)(dx + (size_t)row * D);
   uint2* dyr = dy ? (uint2*)(dy + (size_t)row * D) : nullptr;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
@@ -113,10 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       r.y = rs * (g[i].y - c1 - v[i].y * c2);
       r.z = rs * (g[i].z - c1 - v[i].z * c2);
       r.w = rs * (g[i].w - c1 - v[i].w * c2);
-      if (accumulate) {
-        const float4 o = dxr[idx];
-        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
-      }
+      r.x += o[i].x; r.y += o[i].y; r.z += o[i].z; r.w += o[i].w;
       dxr[idx] = r;
       if (dyr) {
         const float4 gm = ((const float4*)gamma_next)[idx];
