@@ -153,15 +153,16 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const uint4 zero = make_uint4(0, 0, 0, 0);
   int k = wave * 32;                       // this wave's k-steps: wave, wave + 4, wave + 8, ...
-  for (; k + 7 * 128 + 32 <= K; k += 8 * 128) {
-    uint4 xa[8], wb[8];
+  constexpr int U = 6;                     // k-steps in flight per wave (K = 1536: 12 per wave = two full rounds, no tail)
+  for (; k + (U - 1) * 128 + 32 <= K; k += U * 128) {
+    uint4 xa[U], wb[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       xa[u] = rok ? *(const uint4*)(xp + k + 128 * u) : zero;
       wb[u] = wok ? *(const uint4*)(wp + k + 128 * u) : zero;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&xa[u], *(bf16x8*)&wb[u], acc, 0, 0, 0);
   }
   for (; k < K; k += 128) {
