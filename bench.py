@@ -221,7 +221,7 @@ def main():
     if rank == 0:
         if probe["n"]:
             ach = probe["flops"] / (probe["ms"] * 1e-3)
-            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,2,2,DENSE,STORE>",
+            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE>",
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16, 4), "traffic": pmc_traffic(), "launches": probe["n"],
                                "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
@@ -241,7 +241,7 @@ def pmc_traffic():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             k = json.load(f)["kernels"]
         for name, v in k.items():
-            if "gemm_kernel<256, 128, 2, 2, 0, 0>" in name:
+            if "gemm_kernel<256, 128, 4, 2, 0, 0>" in name:
                 return round(v["hbm_bytes_per_launch_corrected"])
     except Exception:  # noqa: BLE001
         pass

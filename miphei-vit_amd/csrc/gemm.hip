@@ -49,13 +49,15 @@ static int select_variant(const mvit_gemm_args& a) {
   static const int huge_min_tiles = [] { const char* e = getenv("MVIT_GEMM_HUGE_MIN_TILES"); return e ? atoi(e) : 600; }();
   const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const bool huge = big && dense && (a.N % 256 == 0) && tiles256 >= huge_min_tiles && a.ksplit <= 1;
-  // one-wave-per-SIMD variants (4 waves, 128-row sub-tiles, register-double-buffered fragments): MVIT_GEMM_W4 bit 0
-  // forces the 256x256 one, bit 1 the 256x128 one, 4 disables them.  By default the 256x128 one takes the long-K
-  // problems, where its cheaper K step outweighs its dearer epilogue (measured: tools/epi_probe.py).
+  // one-wave-per-SIMD variants (4 waves, 128-row sub-tiles), kept for measurement: MVIT_GEMM_W4 bit 0 sends the 256x256
+  // problems there, bit 1 every dense 256x128 problem, bit 3 (8) the long-K (>= 4096) ones.  Off by default: since the
+  // 8-wave tiles run the same explicitly ordered, register-double-buffered K step they are as fast in the main loop and
+  // cheaper in the epilogue (tools/bench_vs_blas.py; whole step 41.3 vs 42.1 ms).
   static const int w4 = [] { const char* e = getenv("MVIT_GEMM_W4"); return e ? atoi(e) : 0; }();
   auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
   if (huge) return (w4 & 1) ? id(256, 256, 2, 2) : id(256, 256, 2, 4);
-  if (big && dense && (a.N % 128 == 0) && (a.epi != MVIT_EPI_SWIGLU || (w4 & 16)) && ((w4 & 2) || (!(w4 & 4) && a.K >= 4096 && a.ksplit <= 1)))
+  if (big && dense && (a.N % 128 == 0) && (a.epi != MVIT_EPI_SWIGLU || (w4 & 16)) && a.ksplit <= 1 &&
+      ((w4 & 2) || ((w4 & 8) && a.K >= 4096)))
     return id(256, 128, 2, 2);
   if (a.epi == MVIT_EPI_SWIGLU) {
     if ((a.N % 128) || !dense) return -1;

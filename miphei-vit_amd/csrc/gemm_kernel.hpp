@@ -40,6 +40,13 @@ constexpr size_t gemm_lds_bytes() {
   return (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
 }
 
+#ifndef MVIT_ABLATE
+#define MVIT_ABLATE 0
+#endif
+#ifndef MVIT_GEMM_SEQ
+#define MVIT_GEMM_SEQ 1
+#endif
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit_gemm_args p) {
   constexpr int NW = WAVES_M * WAVES_N;
@@ -53,7 +60,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
   constexpr int SLD = WTN + 4;                // epilogue panel row stride (floats)
   constexpr int SLAB = 16 * SLD;              // 16-row slab per wave
-  constexpr bool PIPE = NW == 4 && WTM == 128;  // one wave per SIMD: register-double-buffered fragment pipeline
+#ifndef MVIT_GEMM_PIPE8
+#define MVIT_GEMM_PIPE8 1
+#endif
+  // register-double-buffered fragment pipeline with an explicit instruction order: one wave per SIMD (4 waves, 128-row
+  // sub-tiles) and, with MVIT_GEMM_PIPE8, the 8-wave 256-row tiles too
+  constexpr bool PIPE = (NW == 4 && WTM == 128) || (MVIT_GEMM_PIPE8 && NW == 8 && BM == 256);
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
   static_assert((size_t)NW * SLAB * 4 + (size_t)WAVES_M * BN * 8 <= (size_t)BUF_BYTES, "epilogue panel must fit one LDS buffer");
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -231,6 +243,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // loop spread the DMA issue of a K tile over its MFMA sub-steps
   auto issue_pieces_fast = [&](int t, int buf, auto p0_tag, auto p1_tag) __attribute__((always_inline)) {
     constexpr int P0 = decltype(p0_tag)::value, P1 = decltype(p1_tag)::value;
+#if MVIT_ABLATE & 1  // measurement build (tools/gemm_ablate.py): no operand DMA inside the pinned loop
+    return;
+#endif
     char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
     char* b = a + A_BYTES;
     const int soff = t * (BK * 2);
@@ -304,6 +319,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         boff[s_] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + frag_row) * 128u + sw;
       }
       auto load_frags = [&](const char* a, const char*, int s_, bf16x8 (&xa)[TM], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+#if MVIT_ABLATE & 2  // measurement build: fragments stay whatever the first read left in the registers
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(xa[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "=v"(xb[j]));
+        return;
+#endif
         const char* pa = a + aoff[s_];
         const char* pb = a + boff[s_];
 #pragma unroll
@@ -312,6 +334,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int j = 0; j < TN; ++j) xb[j] = *(const bf16x8*)(pb + j * 4096);
       };
       auto mma = [&](const bf16x8 (&xa)[TM], const bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+#if MVIT_ABLATE & 4  // measurement build: operand movement only
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xa[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(xb[j]));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -333,6 +362,93 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       __builtin_amdgcn_s_barrier();
       load_frags(smem + cb * BUF_BYTES, smem + cb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
       constexpr int PG = (LPT + 2) / 3;  // DMA pieces per sub-step
+#if MVIT_GEMM_SEQ
+      // Explicit instruction order for the tight steps: every MFMA is followed by at most one or two companion operations
+      // (a fragment read for the next sub-step, in the order the next sub-step consumes them, or one DMA piece of the
+      // refill), and sched_barrier(0) keeps hipcc from regrouping them into bursts.
+      auto issue_piece = [&](int t, int buf, int j, auto) __attribute__((always_inline)) {
+        char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
+        char* b = a + A_BYTES;
+        const int soff = t * (BK * 2);
+        const unsigned sa = (unsigned)(RPI * 2) * (unsigned)p.lda, sb = (unsigned)(RPI * 2) * (unsigned)p.ldb;
+        if (j < A_CH) {
+          unsigned off = (validA >> j) & 1 ? baseA + (unsigned)j * sa : OOB;
+          asm volatile("" : "+v"(off));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, soff, 0, 0);
+        } else {
+          const int jb = j - A_CH;
+          unsigned off = (validB >> jb) & 1 ? baseB + (unsigned)jb * sb : OOB;
+          asm volatile("" : "+v"(off));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + jb * RPI * 128), 16, off, soff, 0, 0);
+        }
+      };
+      auto sub_seq = [&](const bf16x8 (&ca)[TM], const bf16x8 (&cbf)[TN], bf16x8 (&na)[TM], bf16x8 (&nbf)[TN],
+                         const char* rbase, int rs, int t, int p0, int p1, int mf0, int mf1, auto tag) __attribute__((always_inline)) {
+        // MFMAs [mf0, mf1) of the sub-step; the companions (all NR reads when mf1 is the end, DMA pieces [p0, p1)) are spread over them
+        constexpr int NR = TM + TN, NM = TM * TN;
+        const int ND = p1 - p0, C = (mf1 == NM ? NR : 0) + ND, NMr = mf1 - mf0;
+        const char* pa = rbase + aoff[rs];
+        const char* pb = rbase + boff[rs];
+#pragma unroll
+        for (int m = mf0; m < mf1; ++m) {
+          const int i = m / TN, j = m % TN;
+#if MVIT_ABLATE & 4
+          asm volatile("" ::"v"(ca[i]), "v"(cbf[j]));
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], cbf[j], acc[i][j], 0, 0, 0);
+#endif
+#pragma unroll
+          for (int c = 0; c < NR + PG; ++c) {
+            if (c < C && c * NMr / C == m - mf0) {
+              const int before = c * ND / C;
+              if ((c + 1) * ND / C > before) {
+#if !(MVIT_ABLATE & 1)
+                issue_piece(t + NSTAGE - 1, ib, p0 + before, tag);
+#endif
+              } else {
+                const int r = c - before;
+#if MVIT_ABLATE & 2
+                if (r >= 0) {
+                } else
+#endif
+                if (r == 0)
+                  na[0] = *(const bf16x8*)(pa);
+                else if (r <= TN)
+                  nbf[r - 1] = *(const bf16x8*)(pb + (r - 1) * 4096);
+                else
+                  na[r - TN] = *(const bf16x8*)(pa + (r - TN) * 4096);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto kstep_seq = [&](int t, auto tag) __attribute__((always_inline)) {
+        const char* a = smem + cb * BUF_BYTES;
+        constexpr int Q1 = PG < LPT ? PG : LPT, Q2 = 2 * PG < LPT ? 2 * PG : LPT;
+        constexpr int NM = TM * TN;
+#ifndef MVIT_GEMM_HO
+#define MVIT_GEMM_HO 3
+#endif
+        constexpr int HO = MVIT_GEMM_HO;  // MFMAs of the last sub-step issued before the hand-over (its fragment reads have time to land)
+        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, t, 0, Q1, 0, NM, tag);
+        sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, t, Q1, Q2, 0, NM, tag);
+        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, t, Q2, LPT, 0, NM, tag);
+        if (HO > 0) sub_seq(fa[1], fb[1], fa[0], fb[0], a, 0, t, 0, 0, 0, HO, tag);
+        const int nb = cb + 1 == NSTAGE ? 0 : cb + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (NSTAGE == 3)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        sub_seq(fa[1], fb[1], fa[0], fb[0], smem + nb * BUF_BYTES, 0, t, 0, 0, HO, NM, tag);
+        cb = nb;
+        ib = ib + 1 == NSTAGE ? 0 : ib + 1;
+      };
+#endif
       auto kstep = [&](int t, auto tight_tag) __attribute__((always_inline)) {
         constexpr bool tight = decltype(tight_tag)::value;
         const char* a = smem + cb * BUF_BYTES;
@@ -390,7 +506,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       int t = t_begin;
       if (AMODE == MVIT_A_DENSE) {
         const int t_tight = min(t_end, p.K / BK) - (NSTAGE - 1);
+#if MVIT_GEMM_SEQ
+        for (; t < t_tight; ++t) kstep_seq(t, 0);
+#else
         for (; t < t_tight; ++t) kstep(t, std::true_type{});
+#endif
       }
       for (; t < t_end; ++t) kstep(t, std::false_type{});
     } else {

@@ -28,7 +28,7 @@ class _Probe:
 
 
 PROBE = _Probe()
-PROBE_VARIANT = (256 << 20) | (128 << 8) | (2 << 4) | 2   # gemm_kernel<256,128,2,2,...>: largest share of the step
+PROBE_VARIANT = (256 << 20) | (128 << 8) | (4 << 4) | 2   # gemm_kernel<256,128,4,2,...>: largest share of the step
 
 
 def _stream():
@@ -86,7 +86,7 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
         g.patch_P, g.patch_ntok, g.patch_prefix = patch
     g.epi, g.flags, g.ksplit, g.amode = epi, flags, ksplit, amode
     # bench.py's roofline leg: HIP events around the launches that run the dominant instantiation
-    # (gemm_kernel<256,128,2,2,DENSE,STORE>: the K >= 4096 dgrad GEMMs), as reported by the library's own dispatcher
+    # (gemm_kernel<256,128,4,2,DENSE,STORE>: the dgrad GEMMs and the plain-store forward ones), as reported by the library's own dispatcher
     probe = (PROBE.on and amode == A_DENSE and epi == EPI_STORE and ksplit == 1
              and L.lib().mvit_gemm_variant(C.byref(g)) == PROBE_VARIANT)
     if probe:
