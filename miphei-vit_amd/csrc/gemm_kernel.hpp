@@ -46,6 +46,9 @@ constexpr size_t gemm_lds_bytes() {
 #ifndef MVIT_GEMM_SEQ
 #define MVIT_GEMM_SEQ 1
 #endif
+#ifndef MVIT_GEMM_RF
+#define MVIT_GEMM_RF true
+#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit_gemm_args p) {
@@ -366,24 +369,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       // Explicit instruction order for the tight steps: every MFMA is followed by at most one or two companion operations
       // (a fragment read for the next sub-step, in the order the next sub-step consumes them, or one DMA piece of the
       // refill), and sched_barrier(0) keeps hipcc from regrouping them into bursts.
+      // this lane's source offset of every DMA piece of a dense K tile (tile constants; the K advance rides on the scalar
+      // offset): kept in registers across the tight loop so that a piece costs s_mov m0 + buffer_load and nothing else
+      unsigned poff[LPT];
+      auto set_piece_offsets = [&](auto) __attribute__((always_inline)) {  // generic: see issue_tile_fast
+        const unsigned sa = (unsigned)(RPI * 2) * (unsigned)p.lda, sb = (unsigned)(RPI * 2) * (unsigned)p.ldb;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+          poff[j] = j < A_CH ? ((validA >> j) & 1 ? baseA + (unsigned)j * sa : OOB)
+                             : ((validB >> (j - A_CH)) & 1 ? baseB + (unsigned)(j - A_CH) * sb : OOB);
+          asm volatile("" : "+v"(poff[j]));
+        }
+      };
       auto issue_piece = [&](int t, int buf, int j, auto) __attribute__((always_inline)) {
         char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
-        char* b = a + A_BYTES;
         const int soff = t * (BK * 2);
-        const unsigned sa = (unsigned)(RPI * 2) * (unsigned)p.lda, sb = (unsigned)(RPI * 2) * (unsigned)p.ldb;
+        const unsigned off = poff[j];  // (a local on purpose: with the subscript as the builtin's argument the host pass drops the kernel stub)
         if (j < A_CH) {
-          unsigned off = (validA >> j) & 1 ? baseA + (unsigned)j * sa : OOB;
-          asm volatile("" : "+v"(off));
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, soff, 0, 0);
         } else {
-          const int jb = j - A_CH;
-          unsigned off = (validB >> jb) & 1 ? baseB + (unsigned)jb * sb : OOB;
-          asm volatile("" : "+v"(off));
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + jb * RPI * 128), 16, off, soff, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(a + A_BYTES + (j - A_CH) * RPI * 128), 16, off, soff, 0, 0);
         }
       };
       auto sub_seq = [&](const bf16x8 (&ca)[TM], const bf16x8 (&cbf)[TN], bf16x8 (&na)[TM], bf16x8 (&nbf)[TN],
-                         const char* rbase, int rs, int t, int p0, int p1, int mf0, int mf1, auto tag) __attribute__((always_inline)) {
+                         const char* rbase, int rs, int t, int p0, int p1, int mf0, int mf1, bool reads_first, auto tag) __attribute__((always_inline)) {
         // MFMAs [mf0, mf1) of the sub-step; the companions (all NR reads when mf1 is the end, DMA pieces [p0, p1)) are spread over them
         constexpr int NR = TM + TN, NM = TM * TN;
         const int ND = p1 - p0, C = (mf1 == NM ? NR : 0) + ND, NMr = mf1 - mf0;
@@ -400,8 +409,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #pragma unroll
           for (int c = 0; c < NR + PG; ++c) {
             if (c < C && c * NMr / C == m - mf0) {
-              const int before = c * ND / C;
-              if ((c + 1) * ND / C > before) {
+              // DMA pieces evenly between the reads, or (last sub-step before the hand-over) after all of them
+              const int before = reads_first ? (c < NR ? 0 : c - NR) : c * ND / C;
+              if (reads_first ? c >= NR : (c + 1) * ND / C > before) {
 #if !(MVIT_ABLATE & 1)
                 issue_piece(t + NSTAGE - 1, ib, p0 + before, tag);
 #endif
@@ -428,14 +438,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         const char* a = smem + cb * BUF_BYTES;
         constexpr int Q1 = PG < LPT ? PG : LPT, Q2 = 2 * PG < LPT ? 2 * PG : LPT;
         constexpr int NM = TM * TN;
-#ifndef MVIT_GEMM_HO
-#define MVIT_GEMM_HO 3
+        // MFMAs of the last sub-step issued before the hand-over, so that its fragment reads have landed at the barrier and the
+        // next tile's first fragments still get some MFMAs of lead (measured: 1 of 4 and 3 of 8 are the best splits)
+#ifdef MVIT_GEMM_HO
+        constexpr int HO = MVIT_GEMM_HO;
+#else
+        constexpr int HO = NM * 3 / 8;
 #endif
-        constexpr int HO = MVIT_GEMM_HO;  // MFMAs of the last sub-step issued before the hand-over (its fragment reads have time to land)
-        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, t, 0, Q1, 0, NM, tag);
-        sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, t, Q1, Q2, 0, NM, tag);
-        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, t, Q2, LPT, 0, NM, tag);
-        if (HO > 0) sub_seq(fa[1], fb[1], fa[0], fb[0], a, 0, t, 0, 0, 0, HO, tag);
+        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, t, 0, Q1, 0, NM, false, tag);
+        sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, t, Q1, Q2, 0, NM, false, tag);
+        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, t, Q2, LPT, 0, NM, MVIT_GEMM_RF, tag);
+        if (HO > 0) sub_seq(fa[1], fb[1], fa[0], fb[0], a, 0, t, 0, 0, 0, HO, false, tag);
         const int nb = cb + 1 == NSTAGE ? 0 : cb + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (NSTAGE == 3)
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        sub_seq(fa[1], fb[1], fa[0], fb[0], smem + nb * BUF_BYTES, 0, t, 0, 0, HO, NM, tag);
+        sub_seq(fa[1], fb[1], fa[0], fb[0], smem + nb * BUF_BYTES, 0, t, 0, 0, HO, NM, false, tag);
         cb = nb;
         ib = ib + 1 == NSTAGE ? 0 : ib + 1;
       };
@@ -507,6 +520,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       if (AMODE == MVIT_A_DENSE) {
         const int t_tight = min(t_end, p.K / BK) - (NSTAGE - 1);
 #if MVIT_GEMM_SEQ
+        if (t < t_tight) set_piece_offsets(0);
         for (; t < t_tight; ++t) kstep_seq(t, 0);
 #else
         for (; t < t_tight; ++t) kstep(t, std::true_type{});
