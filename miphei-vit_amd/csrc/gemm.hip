@@ -45,8 +45,10 @@ static int select_variant(const mvit_gemm_args& a) {
   const bool dense = a.amode == MVIT_A_DENSE;
   static const int big_tile = [] { const char* e = getenv("MVIT_GEMM_BIG_TILE"); return e ? atoi(e) : 1; }();
   const bool big = big_tile && a.M >= 1024;  // 8-wave 256x128 tile, 3-stage DMA pipeline
-  // 8-wave 256x256 tile (2 stages): 1.5x the arithmetic intensity per DMA'd byte; only when it still fills the chip
-  static const int huge_min_tiles = [] { const char* e = getenv("MVIT_GEMM_HUGE_MIN_TILES"); return e ? atoi(e) : 600; }();
+  // 8-wave 256x256 tile (2 stages): 1.5x the arithmetic intensity per DMA'd byte, but its two stages leave the refill less
+  // than one K step of lead and M = 5264 quantises badly on it; measured inside the model it wins only from about four
+  // rounds of tiles over the chip (batch-64 inference +0.6 %; the batch-16 training step is 0.8 % faster without it)
+  static const int huge_min_tiles = [] { const char* e = getenv("MVIT_GEMM_HUGE_MIN_TILES"); return e ? atoi(e) : 1024; }();
   const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const bool huge = big && dense && (a.N % 256 == 0) && tiles256 >= huge_min_tiles && a.ksplit <= 1;
   // one-wave-per-SIMD variants (4 waves, 128-row sub-tiles), kept for measurement: MVIT_GEMM_W4 bit 0 sends the 256x256
