@@ -22,7 +22,11 @@ def _rand(*shape, scale=1.0, seed=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (329, 192, 96), (5264, 1536, 1536), (700, 64, 72), (1000, 48, 432),
-                                   (513, 32, 648), (260, 96, 64), (130, 288, 64)])
+                                   (513, 32, 648), (260, 96, 64), (130, 288, 64),
+                                   # 256-row tiles (M >= 1024): ragged M / N / K, K shorter than the DMA ring, one K tile,
+                                   # a K tail behind the explicitly ordered steps, the 256x256 tile (>= 1024 tiles)
+                                   (1100, 200, 200), (2000, 384, 136), (1500, 256, 1000), (1024, 128, 64), (1300, 640, 72),
+                                   (8192, 8192, 136)])
 def test_gemm_store(M, N, K):
     ops = _ops()
     a = _rand(M, K, seed=1).bfloat16()
@@ -42,9 +46,9 @@ def test_gemm_store(M, N, K):
     assert torch.equal(cf, ai.float() @ bi.float().t())
 
 
-def test_gemm_kext_and_splitk():
+@pytest.mark.parametrize("M,N,K,K2", [(700, 384, 256, 16), (2100, 384, 1536, 16), (1300, 256, 200, 16)])
+def test_gemm_kext_and_splitk(M, N, K, K2):
     ops = _ops()
-    M, N, K, K2 = 700, 384, 256, 16
     a, b = _rand(M, K, seed=1).bfloat16(), _rand(N, K, seed=2).bfloat16()
     a2, b2 = _rand(M, K2, seed=3).bfloat16(), _rand(N, K2, seed=4).bfloat16()
     ref = a.float() @ b.float().t() + a2.float() @ b2.float().t()
@@ -129,7 +133,8 @@ def test_gemm_swiglu_fwd_bwd():
 
 
 @pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),
-                                                 (1, 24, 24, 72, 32, 1), (3, 8, 8, 1728, 256, 1)])
+                                                 (1, 24, 24, 72, 32, 1), (3, 8, 8, 1728, 256, 1),
+                                                 (1, 64, 64, 48, 128, 1), (2, 72, 72, 40, 96, 2)])  # 256-row conv tiles
 def test_conv3x3_fwd_stats_and_dgrad(B, H, W, C, Cout, stride):
     ops = _ops()
     x = _rand(B, H, W, C, seed=1).bfloat16()  # NHWC
