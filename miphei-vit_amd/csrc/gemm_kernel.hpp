@@ -46,8 +46,8 @@ constexpr size_t gemm_lds_bytes() {
 #ifndef MVIT_GEMM_SEQ
 #define MVIT_GEMM_SEQ 1
 #endif
-#ifndef MVIT_GEMM_RF
-#define MVIT_GEMM_RF true
+#ifndef MVIT_GEMM_PREISSUE
+#define MVIT_GEMM_PREISSUE 1
 #endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
@@ -392,7 +392,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         }
       };
       auto sub_seq = [&](const bf16x8 (&ca)[TM], const bf16x8 (&cbf)[TN], bf16x8 (&na)[TM], bf16x8 (&nbf)[TN],
-                         const char* rbase, int rs, int t, int p0, int p1, int mf0, int mf1, bool reads_first, auto tag) __attribute__((always_inline)) {
+                         const char* rbase, int rs, int dt, int dbuf, int p0, int p1, int mf0, int mf1, bool reads_first, auto tag) __attribute__((always_inline)) {
+        // dt / dbuf: K tile and LDS buffer of the DMA pieces [p0, p1)
         // MFMAs [mf0, mf1) of the sub-step; the companions (all NR reads when mf1 is the end, DMA pieces [p0, p1)) are spread over them
         constexpr int NR = TM + TN, NM = TM * TN;
         const int ND = p1 - p0, C = (mf1 == NM ? NR : 0) + ND, NMr = mf1 - mf0;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
               const int before = reads_first ? (c < NR ? 0 : c - NR) : c * ND / C;
               if (reads_first ? c >= NR : (c + 1) * ND / C > before) {
 #if !(MVIT_ABLATE & 1)
-                issue_piece(t + NSTAGE - 1, ib, p0 + before, tag);
+                issue_piece(dt, dbuf, p0 + before, tag);
 #endif
               } else {
                 const int r = c - before;
@@ -434,7 +435,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           __builtin_amdgcn_sched_barrier(0);
         }
       };
-      auto kstep_seq = [&](int t, auto tag) __attribute__((always_inline)) {
+      // `pre`: the first piece group of this step's refill was already issued behind the previous step's hand-over;
+      // `nxt`: issue the first group of the NEXT step's refill behind this step's hand-over (into the buffer the hand-over has
+      // just freed).  The refill of a step thus runs from the previous hand-over to the end of sub-step 1 instead of over
+      // sub-steps 0-2: half a K step more lead, which the two-stage 256x256 tile needs (its refill must land within the step).
+      auto kstep_seq = [&](int t, auto pre_tag, auto nxt_tag) __attribute__((always_inline)) {
+        constexpr bool pre = decltype(pre_tag)::value, nxt = decltype(nxt_tag)::value;
         const char* a = smem + cb * BUF_BYTES;
         constexpr int Q1 = PG < LPT ? PG : LPT, Q2 = 2 * PG < LPT ? 2 * PG : LPT;
         constexpr int NM = TM * TN;
@@ -445,10 +451,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #else
         constexpr int HO = NM * 3 / 8;
 #endif
-        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, t, 0, Q1, 0, NM, false, tag);
-        sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, t, Q1, Q2, 0, NM, false, tag);
-        sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, t, Q2, LPT, 0, NM, MVIT_GEMM_RF, tag);
-        if (HO > 0) sub_seq(fa[1], fb[1], fa[0], fb[0], a, 0, t, 0, 0, 0, HO, false, tag);
+        const int rt = t + NSTAGE - 1;  // tile of this step's refill, into buffer ib
+        if constexpr (pre) {
+          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, rt, ib, Q1, Q2, 0, NM, false, 0);
+          sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, rt, ib, Q2, LPT, 0, NM, false, 0);
+          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, rt, ib, 0, 0, 0, NM, false, 0);
+        } else {
+          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, rt, ib, 0, Q1, 0, NM, false, 0);
+          sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, rt, ib, Q1, Q2, 0, NM, false, 0);
+          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, rt, ib, Q2, LPT, 0, NM, true, 0);
+        }
+        if (HO > 0) sub_seq(fa[1], fb[1], fa[0], fb[0], a, 0, rt, ib, 0, 0, 0, HO, false, 0);
         const int nb = cb + 1 == NSTAGE ? 0 : cb + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (NSTAGE == 3)
@@ -457,7 +470,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        sub_seq(fa[1], fb[1], fa[0], fb[0], smem + nb * BUF_BYTES, 0, t, 0, 0, HO, NM, false, tag);
+        // behind the hand-over: first fragments of the next tile, then (nxt) the first pieces of tile t + NSTAGE into the buffer
+        // every wave has just finished reading (the one this step consumed)
+        sub_seq(fa[1], fb[1], fa[0], fb[0], smem + nb * BUF_BYTES, 0, t + NSTAGE, cb, 0, nxt ? Q1 : 0, HO, NM, true, 0);
         cb = nb;
         ib = ib + 1 == NSTAGE ? 0 : ib + 1;
       };
@@ -520,8 +535,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       if (AMODE == MVIT_A_DENSE) {
         const int t_tight = min(t_end, p.K / BK) - (NSTAGE - 1);
 #if MVIT_GEMM_SEQ
-        if (t < t_tight) set_piece_offsets(0);
-        for (; t < t_tight; ++t) kstep_seq(t, 0);
+        if (t < t_tight) {
+          set_piece_offsets(0);
+          if (MVIT_GEMM_PREISSUE && NSTAGE == 2 && t + 1 < t_tight) {  // (three stages have the lead anyway: measured 2 % slower there)
+            kstep_seq(t++, std::false_type{}, std::true_type{});
+            for (; t + 1 < t_tight; ++t) kstep_seq(t, std::true_type{}, std::true_type{});
+            kstep_seq(t++, std::true_type{}, std::false_type{});
+          } else {
+            for (; t < t_tight; ++t) kstep_seq(t, std::false_type{}, std::false_type{});
+          }
+        }
 #else
         for (; t < t_tight; ++t) kstep(t, std::true_type{});
 #endif

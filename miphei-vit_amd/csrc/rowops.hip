@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const uint4 zero = make_uint4(0, 0, 0, 0);
   int k = wave * 32;                       // this wave's k-steps: wave, wave + 4, wave + 8, ...
-  constexpr int U = 6;                     // k-steps in flight per wave (K = 1536: 12 per wave = two full rounds, no tail)
+  constexpr int U = 6;                     // k-steps in flight per wave (K = 1536: 12 per wave = two full rounds; 4 and 12 measure the same)
   for (; k + (U - 1) * 128 + 32 <= K; k += U * 128) {
     uint4 xa[U], wb[U];
 #pragma unroll
