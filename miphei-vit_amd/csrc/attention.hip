@@ -91,19 +91,32 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   return r.v;
 }
 
+// Block -> (row block, (batch, head)) coordinates.  The grid is 1-D; hardware places workgroup L on XCD L % 8, and the row
+// blocks of one (batch, head) pair re-read the same K/V (or Q/dO) tiles, so each XCD is given a contiguous run of the
+// pair-major order: the re-reads then hit that XCD's L2 instead of crossing the fabric once per row block
+// (forward: 130 MB -> one pass over q, k, v, o per launch).  Bijective for any block count.
+struct BlockXY { int x, y; };
+__device__ __forceinline__ BlockXY block_xy(int nx) {
+  const int total = gridDim.x, L = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = L & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+  return {wg % nx, wg / nx};
+}
+
 // ------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, AttnDims dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
+  const BlockXY bxy = block_xy((dm.N + 127) / 128);
+  const int bh = bxy.y, b = bh / dm.H, h = bh % dm.H;
   const int N = dm.N, Dh = dm.Dh;
   const size_t rs = (size_t)3 * dm.H * Dh;  // row stride of packed qkv
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
   const bf16_t* kb = qb + (size_t)dm.H * Dh;
   const bf16_t* vb = kb + (size_t)dm.H * Dh;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = bxy.x * 128 + wave * 32;
   const int q = q0 + l31;
 
   // Q fragment (B operand: k = d, col = q)
@@ -249,14 +262,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
+  const BlockXY bxy = block_xy((dm.N + 127) / 128);
+  const int bh = bxy.y, b = bh / dm.H, h = bh % dm.H;
   const int N = dm.N, Dh = dm.Dh;
   const size_t rs = (size_t)3 * dm.H * Dh, ors = (size_t)dm.H * Dh;
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
   const bf16_t* kb = qb + (size_t)dm.H * Dh;
   const bf16_t* vb = kb + (size_t)dm.H * Dh;
   const bf16_t* dob = dO + (size_t)b * N * ors + (size_t)h * Dh;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const int q = bxy.x * 128 + wave * 32 + l31;
 
   bf16x8 qf[4], dof[4];
   float dsum = 0.f;
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     const char* Ks = smem + cur * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
-    if (blockIdx.x * 128 + wave * 32 >= N) continue;  // dead wave (padding rows only)
+    if (bxy.x * 128 + wave * 32 >= N) continue;  // dead wave (padding rows only)
     auto tile_body = [&](auto ragged_tag) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
       const bool kt1_live = !RAGGED || kv0 + 32 < N;
@@ -376,14 +390,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][Q|dO] + L[Npad] + D[Npad] (f32)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.y, b = bh / dm.H, h = bh % dm.H;
+  const BlockXY bxy = block_xy((dm.N + 127) / 128);
+  const int bh = bxy.y, b = bh / dm.H, h = bh % dm.H;
   const int N = dm.N, Dh = dm.Dh;
   const size_t rs = (size_t)3 * dm.H * Dh, ors = (size_t)dm.H * Dh;
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
   const bf16_t* kb = qb + (size_t)dm.H * Dh;
   const bf16_t* vb = kb + (size_t)dm.H * Dh;
   const bf16_t* dob = dO + (size_t)b * N * ors + (size_t)h * Dh;
-  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  const int key = bxy.x * 128 + wave * 32 + l31;
   const int Npad = ((N + KVB - 1) / KVB) * KVB;
   float* LD = (float*)(smem + NRING * 2 * TILE_BYTES);  // L[Npad] (log2 units) then D[Npad]
 
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const char* Ds = Qs + TILE_BYTES;
     const int qt0 = t * KVB;
     const float* Ls = LD + qt0;
-    if (blockIdx.x * 128 + wave * 32 >= N) continue;  // dead wave (padding keys only)
+    if (bxy.x * 128 + wave * 32 >= N) continue;  // dead wave (padding keys only)
     auto tile_body = [&](auto ragged_tag) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
       const bool qt1_live = !RAGGED || qt0 + 32 < N;
@@ -512,7 +527,7 @@ MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, (hipStream_t)stream,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, (hipStream_t)stream,
                      (const bf16_t*)qkv, (bf16_t*)out, lse, dm);
   return MVIT_LAUNCH_CHECK();
 }
@@ -523,7 +538,7 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 127) / 128, B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
                      (const bf16_t*)out, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;
   static size_t lds_raised = 64 * 1024;  // grow-only: the attribute is a per-function maximum
@@ -533,7 +548,7 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_
     if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess)
       return MVIT_EINVAL;
   }
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 127) / 128, B * H), dim3(256), lds_kv, s, (const bf16_t*)qkv,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), lds_kv, s, (const bf16_t*)qkv,
                      (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   return MVIT_LAUNCH_CHECK();
 }
