@@ -91,6 +91,11 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
     a = ap.parse_args()
 
+    # Everything written to stdout while the job runs (RCCL's version banner comes through C stdio, library chatter) is sent
+    # to stderr; the descriptor is restored for the single JSON line at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,10 +232,20 @@ def main():
                                "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
         if not a.no_cpu_baseline and world == 1 and a.mode == "train":
             res["cpu_baseline"], res["parity"] = cpu_baseline(model, a, nc, weights, dev)
-        print(json.dumps(res), flush=True)
+    # RCCL's banner sits in the C-level stdout buffer until that is flushed (normally at exit, i.e. AFTER anything Python
+    # printed): flush it (to stderr, see the top of main) on every rank, tear the group down, then hand stdout back and print
+    # the result as the job's only stdout line.
+    import ctypes
+    libc = ctypes.CDLL(None)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    libc.fflush(None)
+    if rank == 0:
+        os.dup2(real_stdout, 1)
+        print(json.dumps(res), flush=True)
+        os.dup2(2, 1)   # whatever is flushed at interpreter exit stays off stdout
 
 
 def pmc_traffic():
