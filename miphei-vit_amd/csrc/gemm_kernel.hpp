@@ -40,6 +40,12 @@ constexpr size_t gemm_lds_bytes() {
   return (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
 }
 
+// Build-time switches for A/B measurements (tools/gemm_ablate.py, tools/abl/compare_libs.sh); the defaults are the product:
+//   MVIT_ABLATE       bit 0 / 1 / 2: compile the operand DMA / the LDS fragment reads / the MFMAs out of the K step
+//   MVIT_GEMM_SEQ     0: the previous K step (hipcc-scheduled, sched_group_barrier hints) instead of the explicit order
+//   MVIT_GEMM_PIPE8   0: 8-wave tiles on the plain loop (fragments read per sub-step, no register double-buffering)
+//   MVIT_GEMM_PREISSUE 0: two-stage tiles issue their whole refill inside the K step
+//   MVIT_GEMM_HO      n: MFMAs of the last sub-step ahead of the hand-over
 #ifndef MVIT_ABLATE
 #define MVIT_ABLATE 0
 #endif
