@@ -44,10 +44,27 @@ __device__ __forceinline__ unsigned pack2bf(float a, float b) {
 }
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
+// MFMA order inside a sub-step: raster (i major, j minor), or with -DRR_SERP serpentine (j backwards on odd i): then every
+// pair of consecutive MFMAs shares one operand fragment
+#ifdef RR_SERP
+#define JJ(m) ((((m) >> 2) & 1) ? 3 - ((m) & 3) : ((m) & 3))
+#else
+#define JJ(m) ((m) & 3)
+#endif
+// -DRR_TIMING: s_memtime stamps around the four MFMA phases and the three hand-overs of every K tile, summed per wave and
+// written to `prof` by every wave of block 0 (7 sums + tile count); costs ~10 % itself, ratios are what matters
+#ifdef RR_TIMING
+#define STAMP(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; }
+#else
+#define STAMP(k)
+#endif
 
 template <int DUMMY>
 __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                      bf16_t* __restrict__ C, int M, int N, int K) {
+                                                      bf16_t* __restrict__ C, int M, int N, int K, long long* __restrict__ prof) {
+#ifdef RR_TIMING
+  long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -124,23 +141,28 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
       const int b = t & 1;
       const char* cur = smem + b * BUF_BYTES;
       const char* nxt = smem + (b ^ 1) * BUF_BYTES;
+#ifdef RR_TIMING
+      tlast = (long long)__builtin_readcyclecounter();
+#endif
       // ---- phase 1: s = 0 | A fragments of s = 2, 3
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m >> 2], fb[0][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+        acc[m >> 2][JJ(m)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m >> 2], fb[0][JJ(m)], acc[m >> 2][JJ(m)], 0, 0, 0);
         if ((m & 1) == 0) {  // one read per two MFMAs (bunching them into the first eight measured 6 % slower)
           const int r = m >> 1;  // 0..7
           fa[2 + (r >> 2)][r & 3] = *(const bf16x8*)(cur + aoff[2 + (r >> 2)] + (r & 3) * 4096);
         }
         FENCE();
       }
+      STAMP(0)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      STAMP(1)
       FENCE();
       // ---- phase 2: s = 1 | B fragments of s = 2, 3 and the A half of tile t+2
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m >> 2], fb[1][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+        acc[m >> 2][JJ(m)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m >> 2], fb[1][JJ(m)], acc[m >> 2][JJ(m)], 0, 0, 0);
         if ((m & 1) == 0) {
           const int r = m >> 1;
           fb[2 + (r >> 2)][r & 3] = *(const bf16x8*)(cur + boff[2 + (r >> 2)] + (r & 3) * 4096);
@@ -149,16 +171,19 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
         }
         FENCE();
       }
+      STAMP(2)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      STAMP(3)
       FENCE();
       // ---- phase 3: s = 2 | the B half of tile t+2
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][m >> 2], fb[2][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+        acc[m >> 2][JJ(m)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][m >> 2], fb[2][JJ(m)], acc[m >> 2][JJ(m)], 0, 0, 0);
         if (REFILL && (m & 1)) dma(t + 2, b, 8 + (m >> 1), 0);
         FENCE();
       }
+      STAMP(4)
       if (NEXT) {
         if (REFILL)
           asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -167,10 +192,11 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
         __builtin_amdgcn_s_barrier();
         FENCE();
       }
+      STAMP(5)
       // ---- phase 4: s = 3 | fragments of s = 0, 1 of tile t+1 (order of use: A0, B0..B3, A1..A3)
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[3][m >> 2], fb[3][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+        acc[m >> 2][JJ(m)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[3][m >> 2], fb[3][JJ(m)], acc[m >> 2][JJ(m)], 0, 0, 0);
         if (NEXT) {
           const int s = m >> 3, r = m & 7;
           if (r == 0)
@@ -182,6 +208,10 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
         }
         FENCE();
       }
+      STAMP(6)
+#ifdef RR_TIMING
+      tsum[7] += 1;
+#endif
     };
     int t = 0;
     for (; t + 2 < nk; ++t) ktile(t, std::true_type{}, std::true_type{});
@@ -208,6 +238,10 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
     }
     __syncthreads();
   }
+#ifdef RR_TIMING
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; ++k) prof[wave * 8 + k] = tsum[k];
+#endif
 }
 
 static uint16_t f2bf(float f) {
@@ -230,21 +264,23 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
   uint32_t s = 12345;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 9) % 2001 - 1000) / 1000.f; };
-  for (auto& v : hA) v = f2bf(rnd());
-  for (auto& v : hB) v = f2bf(rnd());
+  const bool zeros = getenv("RR_ZEROS") != nullptr;  // all-zero operands: same instruction stream, far less switching power
+  for (auto& v : hA) v = zeros ? 0 : f2bf(rnd());
+  for (auto& v : hB) v = zeros ? 0 : f2bf(rnd());
   bf16_t *dA, *dB, *dC;
   hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)M * N * 2);
   hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+  long long* dProf; hipMalloc(&dProf, 32 * 8); hipMemset(dProf, 0, 32 * 8);
   const int lds = 2 * BUF_BYTES;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const int ntiles = (M / 256) * (N / 256);
   const int grid = ntiles < 256 ? ntiles : 256;
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, dProf);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int it = 20;
   hipEventRecord(e0);
-  for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K);
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, dProf);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
   if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
@@ -262,5 +298,17 @@ int main(int argc, char** argv) {
   }
   printf("gemm_rr M=%d N=%d K=%d: %.1f us  %.1f TF/s  worst sampled rel err %.2e %s\n", M, N, K, ms * 1e3,
          2.0 * M * N * K / (ms * 1e-3) / 1e12, worst, worst < 2e-2 ? "OK" : "MISMATCH");
+#ifdef RR_TIMING
+  long long hp[32]; hipMemcpy(hp, dProf, sizeof(hp), hipMemcpyDeviceToHost);
+  const char* names[7] = {"phase1 MFMA+A reads", "hand-over 1 (lgkm, barrier)", "phase2 MFMA+B reads+DMA A", "hand-over 2 (lgkm, barrier)",
+                          "phase3 MFMA+DMA B", "hand-over 3 (vmcnt, barrier)", "phase4 MFMA+next reads"};
+  for (int w = 0; w < 4; ++w) {
+    printf("wave %d (block 0), cycles per K tile over %lld tiles:", w, hp[w * 8 + 7]);
+    long long tot = 0;
+    for (int k = 0; k < 7; ++k) tot += hp[w * 8 + k];
+    for (int k = 0; k < 7; ++k) printf("  %s %.0f", w == 0 ? names[k] : "", (double)hp[w * 8 + k] / hp[w * 8 + 7]);
+    printf("  | total %.0f\n", (double)tot / hp[w * 8 + 7]);
+  }
+#endif
   return worst < 2e-2 ? 0 : 2;
 }
