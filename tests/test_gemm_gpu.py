@@ -60,9 +60,9 @@ def test_gemm_kext_and_splitk(M, N, K, K2):
     assert _rel(cf, ref) < 1e-5
 
 
-def test_gemm_gelu_resid_patch():
+@pytest.mark.parametrize("M,N,K,P,B", [(329 * 2, 256, 64, 81, 3), (329 * 7, 384, 200, 324, 6)])  # second: 256-row tiles, K tail
+def test_gemm_gelu_resid_patch(M, N, K, P, B):
     ops = _ops()
-    M, N, K = 329 * 2, 256, 64
     a, b, bias = _rand(M, K, seed=1).bfloat16(), _rand(N, K, seed=2, scale=0.2).bfloat16(), _rand(N, seed=3)
     u = a.float() @ b.float().t() + bias
     c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -82,7 +82,7 @@ def test_gemm_gelu_resid_patch():
     ops.gemm(a, b, x, bias=bias, gamma=gam, epi=ops.EPI_RESID)
     assert _rel(x, ref) < 1e-5
     # patch-embed epilogue
-    P, prefix, B = 81, 5, 3
+    prefix = 5
     Mp = B * P
     ap = _rand(Mp, K, seed=7).bfloat16()
     pos = _rand(P, N, seed=8)
@@ -102,9 +102,10 @@ def _pack_swiglu_rows(H):
     return idx
 
 
-def test_gemm_swiglu_fwd_bwd():
+# second case: the 8-wave 256x128 tile of the batch-16 step; third: the 256x256 tile (>= 1024 tiles)
+@pytest.mark.parametrize("M,D,H,Do", [(400, 96, 256, 64), (2100, 200, 384, 136), (8192, 136, 4096, 64)])
+def test_gemm_swiglu_fwd_bwd(M, D, H, Do):
     ops = _ops()
-    M, D, H = 400, 96, 256
     x = _rand(M, D, seed=1).bfloat16()
     w = _rand(2 * H, D, seed=2, scale=0.15)
     bias = _rand(2 * H, seed=3, scale=0.1)
@@ -118,7 +119,6 @@ def test_gemm_swiglu_fwd_bwd():
     assert _rel(g.float(), F.silu(a) * b) < 5e-3
     assert _rel(u.float()[:, idx.argsort()], uref) < 4e-3
     # backward epilogue: dy[M,Dout] @ W2[Dout,H] -> dg, fused d(silu(a)*b)
-    Do = 64
     dy = _rand(M, Do, seed=4).bfloat16()
     w2t = _rand(H, Do, seed=5, scale=0.2).bfloat16()  # [N=H, K=Do]
     du = torch.empty(M, 2 * H, device="cuda", dtype=torch.bfloat16)
