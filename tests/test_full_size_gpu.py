@@ -67,3 +67,43 @@ def test_hoptimus0_batch16_tiles_agree_with_batch2_chunks():
         parts = torch.cat([model(x[i:i + 2]).float() for i in range(0, 16, 2)])
     rel = ((full - parts) ** 2).sum(dim=(0, 2, 3)) / (parts ** 2).sum(dim=(0, 2, 3))
     assert float(rel.max()) < 2e-4, rel     # both are bf16 paths: different tile shapes = different summation order only
+
+
+def test_hoptimus0_three_fused_training_steps_vs_oracle():
+    """ModelModule.training_step (fused HIP step: loss, clip-norm 1.0, Adam(0.5, 0.999, 1e-7), LambdaLR warm-up) on the full
+    H-Optimus-0 configuration against the oracle's restatement of models.py:87-143, three steps: loss, gradient norm, learning
+    rate per step, BatchNorm running statistics and the direction the decoder weights moved."""
+    import bench
+    from oracle import VIT_CONFIGS
+    from oracle.model import OracleTrainer, orion_marker_weights
+    from miphei_vit_amd.generators import get_vitmatte
+    from miphei_vit_amd.loss import WeightedMSELoss
+    from miphei_vit_amd.models import ModelModule
+    nc, B, img, lr_g = 16, 2, 256, 2e-4 * 2 ** 0.5
+    dev = torch.device("cuda:0")
+    with torch.device(dev):
+        model = get_vitmatte("hoptimus0", img, nc, use_lora=True, pretrained=False)
+    bench.synthetic_init_(model, seed=9)
+    w = orion_marker_weights(nc)
+    p0 = {k: v.detach().to("cpu", torch.float32).clone() for k, v in model.state_dict().items()}
+    mod = ModelModule(model, None, lr_g, 0., WeightedMSELoss(50.0, w)).to(dev)
+    mod.total_iters = 1000
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    tr = OracleTrainer(p0, VIT_CONFIGS["hoptimus0"], nc, batch_size=B, total_iters=1000, weights=w)
+    tr.base_lr = lr_g
+    for it in range(3):
+        x, y = bench.synthetic_batch(500 + it, B, img, nc, dev)
+        assert abs(mod.current_lr() - tr.base_lr * (it / 400)) < 1e-12          # linear warm-up, utils.py:217-230
+        loss = float(mod.training_step({"image": x, "target": y}, it))
+        r = tr.step(x.cpu(), y.cpu())
+        assert abs(loss - r["loss"]) < 3e-3 * r["loss"], (it, loss, r["loss"])
+        gn = float(torch.sqrt(model._engine._saved.w.sqn[0]))
+        assert abs(gn - r["grad_norm"]) < 0.05 * r["grad_norm"], (it, gn, r["grad_norm"])
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("decoder.")}
+    for k in ("decoder.fusion_blks.3.conv.bn.running_mean", "decoder.fusion_blks.0.conv.bn.running_var", "decoder.convstream.convs.0.bn.running_mean"):
+        assert float((sd[k] - tr.p[k]).norm() / tr.p[k].norm()) < 2e-2, k
+    # steps 1 and 2 moved the weights (step 0 has lr 0): same direction as the oracle for the shallow, low-noise parameters
+    for k in ("decoder.fusion_blks.3.conv.conv.weight", "decoder.segmentation_head_5.1.weight", "decoder.fusion_blks.2.conv.bn.weight"):
+        d_ref, d_got = (tr.p[k] - p0[k]).flatten().double(), (sd[k] - p0[k]).flatten().double()
+        cos = float((d_ref @ d_got) / (d_ref.norm() * d_got.norm()))
+        assert cos > 0.8 and 0.7 < float(d_got.norm() / d_ref.norm()) < 1.4, (k, cos)
