@@ -49,7 +49,8 @@ def test_hoptimus0_forward_loss_gradnorm_vs_oracle(B, img):
         assert float((g1 - g0).norm() / g0.norm()) < 0.05, k
 
 
-def test_hoptimus0_batch16_tiles_agree_with_batch2_chunks():
+@pytest.mark.parametrize("B", [16, 64])   # 64 = BASELINE configs[4] (inference): fc1 runs the 256x256 tile there
+def test_hoptimus0_batch16_tiles_agree_with_batch2_chunks(B):
     """The batch-16 step runs the 256-row GEMM tiles (M = 5264) and three attention row blocks per pair; the oracle-checked
     batch-2 run above runs the 128-row tiles (M = 658).  In eval mode (running BatchNorm statistics) a tile's prediction does
     not depend on its batch, so the two paths must agree tile by tile, to bf16 rounding."""
@@ -61,10 +62,10 @@ def test_hoptimus0_batch16_tiles_agree_with_batch2_chunks():
         model = get_vitmatte("hoptimus0", img, nc, use_lora=True, pretrained=False)
     bench.synthetic_init_(model, seed=5)
     model.eval()
-    x, _ = bench.synthetic_batch(11, 16, img, nc, dev)
+    x, _ = bench.synthetic_batch(11, B, img, nc, dev)
     with torch.no_grad():
         full = model(x).float()
-        parts = torch.cat([model(x[i:i + 2]).float() for i in range(0, 16, 2)])
+        parts = torch.cat([model(x[i:i + 2]).float() for i in range(0, B, 2)])
     rel = ((full - parts) ** 2).sum(dim=(0, 2, 3)) / (parts ** 2).sum(dim=(0, 2, 3))
     assert float(rel.max()) < 2e-4, rel     # both are bf16 paths: different tile shapes = different summation order only
 
