@@ -65,7 +65,11 @@ static int select_variant(const mvit_gemm_args& a) {
     if ((a.N % 128) || !dense) return -1;
     return big ? id(256, 128, 4, 2) : id(128, 128, 2, 2);
   }
-  if (a.N % 128 == 0 || a.N >= 256) return big ? id(256, 128, 4, 2) : id(128, 128, 2, 2);
+  // N between 65 and 255 that is no multiple of 128 (the decoder's 72- and 176-channel dgrads, K = 288 ... 1584 at a million
+  // rows): 256-row tiles even though up to 44 % of their columns are padding - half as many tiles, and a K loop of 5-25 steps
+  // is mostly per-tile fill and epilogue (+0.3 % on the step)
+  static const int wide_min = [] { const char* e = getenv("MVIT_GEMM_WIDE_MIN"); return e ? atoi(e) : 65; }();
+  if (a.N % 128 == 0 || a.N >= 256 || (big && a.N >= wide_min)) return big ? id(256, 128, 4, 2) : id(128, 128, 2, 2);
   if (a.N > 32) return id(128, 64, 2, 2);
   return id(128, 32, 4, 1);
 }
