@@ -15,6 +15,7 @@
 // Requires M, N multiples of 256 and K a multiple of 64 (>= 192).  Build:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probes/gemm_rr.hip -o tools/probes/gemm_rr ; run: tools/probes/gemm_rr [M N K]
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,13 @@ __device__ __forceinline__ unsigned pack2bf(float a, float b) {
 #endif
 // -DRR_TIMING: s_memtime stamps around the four MFMA phases and the three hand-overs of every K tile, summed per wave and
 // written to `prof` by every wave of block 0 (7 sums + tile count); costs ~10 % itself, ratios are what matters
+// -DRR_NO_READS / -DRR_NO_DMA: compile the fragment reads / the refill DMA out of the K loop (results are garbage): with
+// RR_SECONDS=n (run back to back for n seconds) this gives each part's share of the power budget at the cap
+#ifdef RR_NO_READS
+#define RD(dst, src) asm volatile("" : "+v"(dst))
+#else
+#define RD(dst, src) dst = *(const bf16x8*)(src)
+#endif
 #ifdef RR_TIMING
 #define STAMP(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; }
 #else
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
         acc[m >> 2][JJ(m)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m >> 2], fb[0][JJ(m)], acc[m >> 2][JJ(m)], 0, 0, 0);
         if ((m & 1) == 0) {  // one read per two MFMAs (bunching them into the first eight measured 6 % slower)
           const int r = m >> 1;  // 0..7
-          fa[2 + (r >> 2)][r & 3] = *(const bf16x8*)(cur + aoff[2 + (r >> 2)] + (r & 3) * 4096);
+          RD(fa[2 + (r >> 2)][r & 3], cur + aoff[2 + (r >> 2)] + (r & 3) * 4096);
         }
         FENCE();
       }
@@ -165,9 +173,11 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
         acc[m >> 2][JJ(m)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m >> 2], fb[1][JJ(m)], acc[m >> 2][JJ(m)], 0, 0, 0);
         if ((m & 1) == 0) {
           const int r = m >> 1;
-          fb[2 + (r >> 2)][r & 3] = *(const bf16x8*)(cur + boff[2 + (r >> 2)] + (r & 3) * 4096);
+          RD(fb[2 + (r >> 2)][r & 3], cur + boff[2 + (r >> 2)] + (r & 3) * 4096);
         } else if (REFILL) {
+#ifndef RR_NO_DMA
           dma(t + 2, b, m >> 1, 0);
+#endif
         }
         FENCE();
       }
@@ -180,7 +190,9 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         acc[m >> 2][JJ(m)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][m >> 2], fb[2][JJ(m)], acc[m >> 2][JJ(m)], 0, 0, 0);
+#ifndef RR_NO_DMA
         if (REFILL && (m & 1)) dma(t + 2, b, 8 + (m >> 1), 0);
+#endif
         FENCE();
       }
       STAMP(4)
@@ -200,11 +212,11 @@ __global__ __launch_bounds__(256) void gemm_rr_kernel(const bf16_t* __restrict__
         if (NEXT) {
           const int s = m >> 3, r = m & 7;
           if (r == 0)
-            fa[s][0] = *(const bf16x8*)(nxt + aoff[s]);
+            RD(fa[s][0], nxt + aoff[s]);
           else if (r <= 4)
-            fb[s][r - 1] = *(const bf16x8*)(nxt + boff[s] + (r - 1) * 4096);
+            RD(fb[s][r - 1], nxt + boff[s] + (r - 1) * 4096);
           else
-            fa[s][r - 4] = *(const bf16x8*)(nxt + aoff[s] + (r - 4) * 4096);
+            RD(fa[s][r - 4], nxt + aoff[s] + (r - 4) * 4096);
         }
         FENCE();
       }
@@ -283,6 +295,18 @@ int main(int argc, char** argv) {
   for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, dProf);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
+  if (const char* sec = getenv("RR_SECONDS")) {   // sustained rate at the power cap
+    const double want = atof(sec);
+    hipDeviceSynchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    long n = 0; double dt = 0;
+    while (dt < want) {
+      for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, dProf);
+      hipDeviceSynchronize(); n += 50;
+      dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    printf("sustained over %.1f s: %.1f TF/s\n", dt, 2.0 * M * N * K * n / dt / 1e12);
+  }
   if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
   std::vector<uint16_t> hC((size_t)M * N);
   hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
