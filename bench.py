@@ -6,13 +6,21 @@ A step = one ModelModule.training_step on one synthetic minibatch per rank: HIP 
 encoder with LoRA + ViTMatte decoder, bf16 MFMA / f32 accumulate), fused WeightedMSE, HIP backward, gradient
 all-reduce (RCCL) when N>1, global-norm clip + Adam.  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the instantiation with the
-largest share of the step in profiles/r01_kernel_stats_final.txt: the 4-wave 256x128 MFMA GEMM with the plain store
-epilogue, which runs the K >= 4096 dgrad GEMMs; algorithmic flops / HIP-event durations recorded live during the timed steps) and
-`cpu_baseline` (the CPU oracle = port of the reference arithmetic, timed on this host's cores on a bounded sample).
+largest share of the step in profiles/r02_kernel_stats_train.txt: the 8-wave 256x128 MFMA GEMM with the plain store
+epilogue -- qkv forward and the dgrad GEMMs; algorithmic flops / HIP-event durations recorded live during the timed
+steps), `roofline_step` (whole step, algorithmic FLOPs of SURVEY.md 8d / wall time) and `cpu_baseline` (the CPU oracle =
+port of the reference arithmetic, timed on this host's cores on a bounded sample: 2 warm-ups + median of 5).
+
+`--gpus N` from a plain shell (no WORLD_SIZE in the environment) starts the N ranks itself: the parent never touches
+the GPU, runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, relays rank 0's
+JSON line and exits with the child's code.  `--dry --backend gloo` runs launcher + rendezvous + exchange + timing
+protocol on CPU tensors (used by tests/test_host_cpu.py; it measures nothing).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,6 +33,8 @@ import torch.distributed as dist  # noqa: E402
 FLOPS_TRAIN = {256: 1647.2e9, 512: 7604.0e9}   # SURVEY.md section 8(d), per tile
 FLOPS_FWD = {256: 793.4e9, 512: 3449.1e9}
 FLOPS_ENC = {256: 773.6e9}                       # encoder only (patch embed + 40 blocks)
+ORION_MARKERS = ["Hoechst", "CD31", "CD45", "CD68", "CD4", "FOXP3", "CD8a", "CD45RO", "CD20", "PD-L1", "CD3e", "CD163",
+                 "E-cadherin", "Ki67", "Pan-CK", "SMA"]
 PEAK_BF16 = 2.5e15                                # dense MFMA bf16, MI355X_MICROARCH.md
 
 
@@ -71,37 +81,142 @@ def synthetic_batch(seed, B, S, nc, device):
     return image.contiguous(), target.contiguous()
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (cfg.train.batch_size of the reference)")
     ap.add_argument("--img", type=int, default=256)
     ap.add_argument("--mode", choices=["train", "infer", "embed"], default="train",
                     help="embed = encoder-only class-token embeddings (SURVEY.md 8f row 4, extract_embeddings.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the timed CPU-oracle training step")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-repeats", type=int, default=5, help="timed repetitions of the CPU sample (median), after 2 warm-ups")
+    ap.add_argument("--parity-batch", type=int, default=-1, help="batch of the parity leg (-1: the timed per-GPU batch)")
     ap.add_argument("--encoder", default="hoptimus0")
     ap.add_argument("--generator", choices=["myvitmatte", "unet_lora"], default="myvitmatte",
-                    help="unet_lora = the UNETR baseline of the reference (SURVEY.md 8f row 4); single GPU, no hipGraph")
+                    help="unet_lora = the UNETR baseline of the reference (SURVEY.md 8f row 4)")
     ap.add_argument("--metrics", type=int, default=0, help="train mode: also run the per-step PSNR/SSIM state update of the "
                     "reference (models.py:140-143); the headline number is taken with it off (SURVEY.md section 6)")
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
-    a = ap.parse_args()
+    ap.add_argument("--lora-buckets", type=int, default=4, help="sub-buckets of the LoRA gradient all-reduce (N > 1)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL; gloo only with --dry")
+    ap.add_argument("--dry", action="store_true", help="no GPU work: launcher / rendezvous / exchange / timing protocol on CPU")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch rendezvous port (0: pick a free one)")
+    return ap.parse_args(argv)
+
+
+def self_launch(a, argv):
+    """Plain-shell `bench.py --gpus N`: start the ranks as a child `torch.distributed.run` (never exec: the parent stays a
+    GPU-free supervisor), pass rank 0's stdout through, return the child's exit code."""
+    port = a.master_port
+    if not port:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL across processes on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    out, _ = proc.communicate()
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in out.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode else (0 if lines else 1)
+
+
+def dry_run(a, world, rank):
+    """CPU rehearsal of the multi-rank protocol: rendezvous, broadcast, bucketed exchange with the backward hooks, barriers,
+    MAX-over-ranks timing, one JSON line from rank 0."""
+    import types
+    from miphei_vit_amd.trainer import DataParallelSync
+    if world > 1:
+        dist.init_process_group(a.backend)
+    L, per, ndec = 8, 64, 500
+
+    class Eng:
+        def __init__(self):
+            g = torch.Generator().manual_seed(100 + rank)
+            self._flat = types.SimpleNamespace(flat=torch.full((L * per + ndec,), float(rank)),
+                                               gflat=torch.randn(L * per + ndec, generator=g), n_lora=L * per)
+            self._pack_key = "x"
+
+        def _ensure_flat(self):
+            return self._flat
+
+        def grad_buckets(self):
+            return self._flat.gflat[L * per:], self._flat.gflat[:L * per]
+
+        def lora_blocks(self):
+            return L
+
+    eng = Eng()
+    sync = DataParallelSync(eng, lora_buckets=a.lora_buckets)
+    sync.broadcast_parameters(0)
+    ref = torch.stack([torch.randn(L * per + ndec, generator=torch.Generator().manual_seed(100 + r))
+                       for r in range(world)]).mean(0)
+
+    def step():
+        sync.decoder_ready()
+        for l in range(L - 1, -1, -1):
+            sync.lora_block_done(l)
+        sync.finish()
+
+    g0 = eng._flat.gflat.clone()
+    step()
+    ok = bool(torch.allclose(eng._flat.gflat, ref, atol=1e-6)) and bool((eng._flat.flat == 0).all())
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng._flat.gflat.copy_(g0)
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+        ranks = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": round(world * a.batch * a.steps / dt, 3), "unit": "tiles/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry": True, "exchange_ok": ok,
+                          "rccl_ranks": ranks, "backend": a.backend, "scaling": "weak"}), flush=True)
+    return 0 if ok else 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a, argv)             # before anything touches the GPU
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry:
+        return dry_run(a, world, rank)
+    if a.backend != "nccl":
+        raise SystemExit("--backend gloo is only meaningful with --dry: the product path is RCCL")
 
     # Everything written to stdout while the job runs (RCCL's version banner comes through C stdio, library chatter) is sent
     # to stderr; the descriptor is restored for the single JSON line at the end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_ddp = os.environ.get("MIPHEI_FORCE_DDP", "0") == "1"  # run the RCCL exchange even on one rank (testing)
@@ -114,13 +229,12 @@ def main():
 
     from miphei_vit_amd import ops
     from miphei_vit_amd.generators import get_vitmatte
-    from miphei_vit_amd.loss import WeightedMSELoss
+    from miphei_vit_amd.loss import WeightedMSELoss, marker_weights_from_file
     from miphei_vit_amd.models import ModelModule
     from miphei_vit_amd.trainer import DataParallelSync
 
     nc = 16
-    weights = torch.tensor([1.0, 6.9687, 1.4698, 3.5986, 2.4121, 10.5982, 4.4980, 2.7238, 4.5266, 3.0473, 2.8660, 3.5367,
-                            1.7173, 3.6613, 1.5315, 2.5265])
+    weights = marker_weights_from_file(os.path.join(ROOT, "configs", "channel_stats_orion.json"), ORION_MARKERS)
     if a.mode == "embed":
         from miphei_vit_amd.generators.foundation_models import FOUNDATION_MODEL_REGISTRY
         with torch.device(dev):
@@ -128,8 +242,8 @@ def main():
         synthetic_init_(emb_model, seed=0)
         emb_model = emb_model.eval().half()
     unet = a.generator == "unet_lora"
-    if unet and (world > 1 or a.mode == "embed"):
-        raise SystemExit("--generator unet_lora: single-GPU train / infer modes only")
+    if unet and a.mode == "embed":
+        raise SystemExit("--generator unet_lora: train / infer modes only")
     with torch.device(dev):
         if unet:
             from miphei_vit_amd.generators.unet import Unet
@@ -138,19 +252,18 @@ def main():
             model = get_vitmatte("tiny" if a.mode == "embed" else a.encoder, a.img, nc, use_lora=True, pretrained=False)
     synthetic_init_(model, seed=0)
     eng = model._engine
-    if unet:
+    if unet and not hasattr(eng, "capture_inference"):
         a.graph = 0
     mod = ModelModule(model, None, 2e-4 * a.batch ** 0.5, 0., WeightedMSELoss(50.0, weights)).to(dev)
     mod.total_iters = 100000
-    mod.nan_check_every = 10 ** 9   # the guard's host copy is exercised in tests, not inside the timed region
     mod.update_pix_metrics = bool(a.metrics)
+    sync = None
     if world > 1 or force_ddp:
-        sync = DataParallelSync(eng, force=force_ddp)
+        sync = DataParallelSync(eng, force=force_ddp, lora_buckets=a.lora_buckets, timing=True)
         sync.broadcast_parameters(0)
         mod.grad_sync = sync
     batches = [synthetic_batch(1234 + rank * 1000 + i, a.batch, a.img, nc, dev) for i in range(4)]
 
-    lat = []
     x16 = [b[0].half() for b in batches] if a.mode == "embed" else None
     if a.mode == "infer":
         model.eval()
@@ -175,6 +288,8 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    if sync is not None:
+        sync.exposed_events = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,6 +312,8 @@ def main():
     flops_tile = None if unet else (FLOPS_TRAIN if a.mode == "train" else FLOPS_ENC if a.mode == "embed" else FLOPS_FWD).get(a.img)
 
     cfg_idx = (1 if a.img == 256 else 3) if a.mode == "train" else 4
+    if a.mode == "train" and a.img == 256 and world > 1:
+        cfg_idx = 2
     res = {
         "metric": (f"training tiles/sec ({a.img}x{a.img} H&E->16ch mIF)" if a.mode == "train" else
                    "embedding tiles/sec (encoder only, class token, fp16 in/out)" if a.mode == "embed" else "inference tiles/sec"),
@@ -206,9 +323,15 @@ def main():
         "config": {"workload": (f"UNETR baseline ({a.encoder} + LoRA r8, ViT pyramid + up-conv decoder, 16 heads) " if unet else
                                 f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) ") + f"{a.mode} step, "
                                f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} " +
-                               ("(SURVEY.md 8f row 4)" if a.mode == "embed" else f"(BASELINE.json configs[{cfg_idx}])"),
+                               ("(SURVEY.md 8f row 4)" if a.mode == "embed" or unet else f"(BASELINE.json configs[{cfg_idx}])"),
                    "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}", "pix_metrics": bool(a.metrics)},
     }
+    if dist.is_initialized():
+        res["rccl_ranks"] = dist.get_world_size()
+        if sync is not None and a.mode == "train":
+            ex = sync.exposed_ms()
+            res["exposed_comm_ms_per_step"] = None if ex is None else round(ex, 4)
+            res["config"]["lora_buckets"] = a.lora_buckets
     if a.mode == "infer":
         # p50 latency of one batch, measured after the throughput window with a sync per batch
         ts = []
@@ -223,14 +346,19 @@ def main():
         res["config"]["hipgraph"] = bool(a.graph)
     if flops_tile:
         res["model_flops_frac"] = round(value / world * flops_tile / PEAK_BF16, 4)
+        ach = value / world * flops_tile
+        res["roofline_step"] = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                                "frac": round(ach / PEAK_BF16, 4),
+                                "flops_per_tile": flops_tile, "note": "algorithmic FLOPs of SURVEY.md 8(d) / wall time, per GPU"}
     if rank == 0:
         if probe["n"]:
             ach = probe["flops"] / (probe["ms"] * 1e-3)
-            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE>",
+            traffic, src = pmc_traffic()
+            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE> (8 waves)",
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16, 4), "traffic": pmc_traffic(), "launches": probe["n"],
-                               "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
-        if not a.no_cpu_baseline and world == 1 and a.mode == "train":
+                               "frac": round(ach / PEAK_BF16, 4), "traffic": traffic, "traffic_source": src,
+                               "launches": probe["n"], "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
+        if not a.no_cpu_baseline and world == 1 and a.mode == "train" and not unet:
             res["cpu_baseline"], res["parity"] = cpu_baseline(model, a, nc, weights, dev)
     # RCCL's banner sits in the C-level stdout buffer until that is flushed (normally at exit, i.e. AFTER anything Python
     # printed): flush it (to stderr, see the top of main) on every rank, tear the group down, then hand stdout back and print
@@ -246,52 +374,99 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
         os.dup2(2, 1)   # whatever is flushed at interpreter exit stays off stdout
+    return 0
 
 
 def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE runs, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction; L2-side fabric
-    requests, i.e. Infinity-Cache hits are included).  None when the summary is absent."""
+    """(HBM-side bytes per launch of the dominant kernel, where the figure comes from).  The PMC counters cannot be read from
+    inside the timed run: the value is the committed rocprofv3 summary of this same command (separate FETCH_SIZE / WRITE_SIZE
+    passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of MI355X_MICROARCH.md; L2-side fabric requests, so
+    Infinity-Cache hits are included), newest round first.  (None, None) when no summary is present."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                k = json.load(f)["kernels"]
+            for kn, v in k.items():
+                if "gemm_kernel<256, 128, 4, 2, 0, 0>" in kn:
+                    return round(v["hbm_bytes_per_launch_corrected"]), f"profiles/{name} (static: committed rocprofv3 --pmc passes)"
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
+
+
+def _cpu_model():
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"]
-        for name, v in k.items():
-            if "gemm_kernel<256, 128, 4, 2, 0, 0>" in name:
-                return round(v["hbm_bytes_per_launch_corrected"])
-    except Exception:  # noqa: BLE001
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
         pass
-    return None
+    return "unknown"
+
+
+def _median_time(fn, warmups, repeats):
+    for _ in range(warmups):
+        fn()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
 
 
 def cpu_baseline(model, a, nc, weights, dev):
-    """Time the CPU oracle (port of the reference arithmetic, fp32, all host cores) on a bounded sample -- one training
-    step (forward+backward) at batch `--cpu-batch` of the same workload and weights -- and report the GPU output's parity
-    against it on that sample (eval of the same inputs through the HIP forward with batch statistics)."""
+    """Time the CPU oracle (port of the reference arithmetic, fp32) on a bounded sample of the same workload -- one training step
+    (forward + backward) at batch `--cpu-batch`, same weights: 2 warm-ups, median of `--cpu-repeats` -- and the
+    BASELINE configs[0] tiny case the same way; then check the HIP forward against the oracle forward at the TIMED batch (train-mode
+    BatchNorm, i.e. the tile path the benchmark ran)."""
     from oracle import VIT_CONFIGS
-    from oracle.model import OracleTrainer
+    from oracle.model import OracleTrainer, generator_forward
     cores = min(os.cpu_count() or 1, a.cpu_threads)   # torch-CPU GEMMs stop scaling (and collapse) far below 256 threads
     torch.set_num_threads(cores)
     cfg = VIT_CONFIGS[a.encoder]
     p = {k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()}
     B = a.cpu_batch
     x, y = synthetic_batch(999, B, a.img, nc, dev)
+    xc, yc = x.cpu(), y.cpu()
     tr = OracleTrainer(p, cfg, nc, batch_size=B, total_iters=100000, weights=weights)
     tr.p = p  # no second copy of the 4.6 GB state
-    t0 = time.perf_counter()
-    out_ref, loss_ref, _ = tr.loss_and_grads(x.cpu(), y.cpu())
-    dt = time.perf_counter() - t0
+    med, ts = _median_time(lambda: tr.loss_and_grads(xc, yc), 2, a.cpu_repeats)
+    base = {"value": round(B / med, 4), "unit": "tiles/s", "cores": cores, "host_cores": os.cpu_count(), "cpu_model": _cpu_model(),
+            "kind": "port",
+            "sample": f"training step (fwd+bwd, fp32) of the CPU oracle at batch {B}, same weights: 2 warm-ups, median of "
+                      f"{len(ts)} = {med:.2f} s (min {min(ts):.2f}, max {max(ts):.2f})"}
+    base["tiny"] = cpu_baseline_tiny(cores)
+    # parity at the timed batch: forward only (the backward is covered by tests/test_full_size_gpu.py)
+    PB = a.batch if a.parity_batch < 0 else a.parity_batch
+    xp, _ = synthetic_batch(998, PB, a.img, nc, dev)
+    with torch.no_grad():
+        out_ref = generator_forward(p, xp.cpu(), cfg, nc, training=True)
     model.train()
     with torch.no_grad():
-        out = model._engine.forward(x, train=False, bn_train=True).float().cpu()
+        out = model._engine.forward(xp, train=False, bn_train=True).float().cpu()
     rel = ((out - out_ref) ** 2).sum(dim=(0, 2, 3)) / (out_ref ** 2).sum(dim=(0, 2, 3))
     xm, ym = out - out.mean(dim=(0, 2, 3), keepdim=True), out_ref - out_ref.mean(dim=(0, 2, 3), keepdim=True)
     pear = (xm * ym).sum(dim=(0, 2, 3)) / ((xm ** 2).sum(dim=(0, 2, 3)).sqrt() * (ym ** 2).sum(dim=(0, 2, 3)).sqrt())
-    base = {"value": round(B / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"1 training step (fwd+bwd, fp32) of the CPU oracle at batch {B}, same weights, {dt:.1f} s"}
     parity = {"worst_channel_rel_mse": float(rel.max()), "min_pearson_r": float(pear.min()), "tolerance_rel_mse": 1e-3,
-              "batch": B}
+              "batch": PB}
     return base, parity
 
 
+def cpu_baseline_tiny(cores):
+    """BASELINE.json configs[0]: tiny ViT (2 layers, 64-d, patch 16) + decoder, 4 x 256x256 tiles -> 3 channels, CPU oracle."""
+    from oracle import VIT_CONFIGS, det_state_dict
+    from oracle.model import OracleTrainer, generator_state_shapes, orion_marker_weights
+    cfg = VIT_CONFIGS["tiny"]
+    sd = det_state_dict(generator_state_shapes(cfg, 256, 3), seed=1, layerscale=0.5)
+    p = {k: torch.from_numpy(v) if not torch.is_tensor(v) else v for k, v in sd.items()}
+    x, y = synthetic_batch(997, 4, 256, 3, "cpu")
+    tr = OracleTrainer(p, cfg, 3, batch_size=4, total_iters=100000, weights=orion_marker_weights(3))
+    med, ts = _median_time(lambda: tr.loss_and_grads(x, y), 2, 5)
+    return {"value": round(4 / med, 3), "unit": "tiles/s", "cores": cores,
+            "sample": f"BASELINE configs[0]: tiny ViT + decoder training step, 4 x 256x256 -> 3 ch, median of 5 = {med:.3f} s"}
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

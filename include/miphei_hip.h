@@ -217,10 +217,13 @@ MVIT_API int mvit_wmse_fwd_bwd(const float* pred, const float* target, const flo
                                int C, long long HW, float lambda_factor, mvit_stream_t stream);
 MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t stream);
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step on flat f32 buffers (src/models.py:136-138,359-371);
- * sqnorm = device scalar holding sum g^2 (no host sync), bias_c{1,2} = 1-beta^t. */
+ * sqnorm = device scalar holding sum g^2 (no host sync), bias_c{1,2} = 1-beta^t.
+ * NaN guard (src/models.py:102-105, `isnan(fake)` -> save weights -> raise): when *sqnorm is NaN/Inf, or *nonfinite_flag is
+ * already set, the launch changes nothing and sets *nonfinite_flag = 1 (device int, sticky, may be NULL); the host reads the
+ * flag asynchronously and finds the last finite weights in p. */
 MVIT_API int mvit_adam_clip_step(float* p, const float* g, float* m, float* v, const double* sqnorm, long long n, float lr,
                                  float beta1, float beta2, float eps, float bias_c1, float bias_c2, float max_norm,
-                                 mvit_stream_t stream);
+                                 int* nonfinite_flag, mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- on-device input / output stage */
 /* dst(f32 NCHW)[b,c,p] = src(u8 NHWC)[b,p,c] * scale[c] + shift[c].  With scale = 1/std, shift = -mean/std this is

@@ -541,13 +541,8 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
                      (const bf16_t*)out, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;
-  static size_t lds_raised = 64 * 1024;  // grow-only: the attribute is a per-function maximum
-  if (lds_kv > lds_raised) {
-    if (lds_kv > 160 * 1024) return MVIT_EINVAL;
-    lds_raised = lds_kv;
-    if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv) != hipSuccess)
-      return MVIT_EINVAL;
-  }
+  static mvit_per_device_size lds_raised;  // grow-only per device: the attribute is a per-function, per-device maximum
+  if (mvit_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel, lds_kv, lds_raised) != MVIT_OK) return MVIT_EINVAL;
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), lds_kv, s, (const bf16_t*)qkv,
                      (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   return MVIT_LAUNCH_CHECK();

@@ -47,6 +47,28 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// Host-side per-device state.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are properties of the CURRENT
+// device, so anything cached about them is keyed by hipGetDevice() (a process may drive several GPUs, from several threads).
+// Relaxed atomics are enough: the cached value only ever grows and re-applying an attribute is idempotent.
+#include <atomic>
+#define MVIT_MAX_DEVICES 64
+struct mvit_per_device_size {
+  std::atomic<size_t> v[MVIT_MAX_DEVICES];
+};
+// Make sure kernel `fn` may be launched with `bytes` of dynamic LDS on the current device (no-op below the 64 KB default).
+static inline int mvit_ensure_dynamic_lds(const void* fn, size_t bytes, mvit_per_device_size& raised) {
+  if (bytes <= 64 * 1024) return MVIT_OK;
+  if (bytes > 160 * 1024) return MVIT_EINVAL;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return MVIT_EINVAL;
+  if (bytes <= raised.v[dev].load(std::memory_order_relaxed)) return MVIT_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return MVIT_EINVAL;
+  size_t cur = raised.v[dev].load(std::memory_order_relaxed);
+  while (cur < bytes && !raised.v[dev].compare_exchange_weak(cur, bytes, std::memory_order_relaxed)) {
+  }
+  return MVIT_OK;
+}
+
 static inline int hip_ok(hipError_t e) { return e == hipSuccess ? MVIT_OK : (int)e; }
 #define MVIT_LAUNCH_CHECK() hip_ok(hipGetLastError())
 // hipGetLastError() reports (and resets) the last error of ANY earlier HIP call of this thread, including benign

@@ -6,13 +6,15 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s);
 
 namespace mvit_gemm {
 int gemm_num_cus() {
-  static const int n = [] {
-    int dev = 0, cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-      cu = 256;
-    return cu;
-  }();
-  return n;
+  static std::atomic<int> cus[MVIT_MAX_DEVICES];  // per device (zero = not asked yet)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return 256;
+  int cu = cus[dev].load(std::memory_order_relaxed);
+  if (cu <= 0) {
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    cus[dev].store(cu, std::memory_order_relaxed);
+  }
+  return cu;
 }
 }  // namespace mvit_gemm
 
@@ -40,22 +42,30 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   return dispatch(al, s);
 }
 
+// Measurement knobs of the tile dispatch.  The product build compiles them to their constants: which kernel runs depends only on
+// the problem.  `make DEBUG_KNOBS=1` (-DMVIT_DEBUG_KNOBS) reads them from the environment for A/B runs (tools/).
+#ifdef MVIT_DEBUG_KNOBS
+#define MVIT_KNOB(var, env, dflt) static const int var = [] { const char* e = getenv(env); return e ? atoi(e) : (dflt); }()
+#else
+#define MVIT_KNOB(var, env, dflt) constexpr int var = (dflt)
+#endif
+
 // tile variant for a problem: (BM << 20) | (BN << 8) | (WAVES_M << 4) | WAVES_N, or -1
 static int select_variant(const mvit_gemm_args& a) {
   const bool dense = a.amode == MVIT_A_DENSE;
-  static const int big_tile = [] { const char* e = getenv("MVIT_GEMM_BIG_TILE"); return e ? atoi(e) : 1; }();
+  MVIT_KNOB(big_tile, "MVIT_GEMM_BIG_TILE", 1);
   const bool big = big_tile && a.M >= 1024;  // 8-wave 256x128 tile, 3-stage DMA pipeline
   // 8-wave 256x256 tile (2 stages): 1.5x the arithmetic intensity per DMA'd byte, but its two stages leave the refill less
   // than one K step of lead and M = 5264 quantises badly on it; measured inside the model it wins only from about four
   // rounds of tiles over the chip (batch-64 inference +0.6 %; the batch-16 training step is 0.8 % faster without it)
-  static const int huge_min_tiles = [] { const char* e = getenv("MVIT_GEMM_HUGE_MIN_TILES"); return e ? atoi(e) : 1024; }();
+  MVIT_KNOB(huge_min_tiles, "MVIT_GEMM_HUGE_MIN_TILES", 1024);
   const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const bool huge = big && dense && (a.N % 256 == 0) && tiles256 >= huge_min_tiles && a.ksplit <= 1;
   // one-wave-per-SIMD variants (4 waves, 128-row sub-tiles), kept for measurement: MVIT_GEMM_W4 bit 0 sends the 256x256
   // problems there, bit 1 every dense 256x128 problem, bit 3 (8) the long-K (>= 4096) ones.  Off by default: since the
   // 8-wave tiles run the same explicitly ordered, register-double-buffered K step they are as fast in the main loop and
   // cheaper in the epilogue (tools/bench_vs_blas.py; whole step 41.3 vs 42.1 ms).
-  static const int w4 = [] { const char* e = getenv("MVIT_GEMM_W4"); return e ? atoi(e) : 0; }();
+  MVIT_KNOB(w4, "MVIT_GEMM_W4", 0);
   auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
   if (huge) return (w4 & 1) ? id(256, 256, 2, 2) : id(256, 256, 2, 4);
   if (big && dense && (a.N % 128 == 0) && (a.epi != MVIT_EPI_SWIGLU || (w4 & 16)) && a.ksplit <= 1 &&
@@ -68,7 +78,7 @@ static int select_variant(const mvit_gemm_args& a) {
   // N between 65 and 255 that is no multiple of 128 (the decoder's 72- and 176-channel dgrads, K = 288 ... 1584 at a million
   // rows): 256-row tiles even though up to 44 % of their columns are padding - half as many tiles, and a K loop of 5-25 steps
   // is mostly per-tile fill and epilogue (+0.3 % on the step)
-  static const int wide_min = [] { const char* e = getenv("MVIT_GEMM_WIDE_MIN"); return e ? atoi(e) : 65; }();
+  MVIT_KNOB(wide_min, "MVIT_GEMM_WIDE_MIN", 65);
   if (a.N % 128 == 0 || a.N >= 256 || (big && a.N >= wide_min)) return big ? id(256, 128, 4, 2) : id(128, 128, 2, 2);
   if (a.N > 32) return id(128, 64, 2, 2);
   return id(128, 32, 4, 1);

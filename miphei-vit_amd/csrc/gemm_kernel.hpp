@@ -878,14 +878,8 @@ int launch_one(const mvit_gemm_args& a, hipStream_t s) {
   if (gx > tiles) gx = tiles;
   dim3 grid(gx, 1, a.ksplit > 1 ? a.ksplit : 1);
   auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
-  if (lds > 64 * 1024) {
-    static bool raised = false;  // per instantiation
-    if (!raised) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MVIT_EINVAL;
-      raised = true;
-    }
-  }
+  static mvit_per_device_size raised;  // per instantiation, per device
+  if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return MVIT_EINVAL;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);
   return MVIT_LAUNCH_CHECK();
 }

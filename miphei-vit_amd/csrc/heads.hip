@@ -998,12 +998,8 @@ MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, 
                                  int W, int NH, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (B <= 0 || H <= 0 || W <= 0 || NH <= 0 || NH > MAXH) return MVIT_EINVAL;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute((const void*)conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_LDS) != hipSuccess)
-      return MVIT_EINVAL;
-    raised = true;
-  }
+  static mvit_per_device_size raised;
+  if (mvit_ensure_dynamic_lds((const void*)conv_fwd_kernel, CF_LDS, raised) != MVIT_OK) return MVIT_EINVAL;
   const long long blocks = (long long)B * ((H + CF_TH - 1) / CF_TH) * ((W + CF_TW - 1) / CF_TW);
   if (blocks >= (1ll << 30)) return MVIT_EINVAL;
   hipLaunchKernelGGL(conv_fwd_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(512), CF_LDS, (hipStream_t)stream,

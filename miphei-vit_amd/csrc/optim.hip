@@ -64,11 +64,22 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, const double* __restrict__ sqnorm, long long n,
                                                    float lr, float b1, float b2, float eps, float bc1, float bc2,
-                                                   float max_norm) {
+                                                   float max_norm, int* __restrict__ nonfinite) {
   float coef = 1.f;
-  if (sqnorm && max_norm > 0.f) {
-    const float tn = (float)sqrt(*sqnorm);
-    coef = fminf(1.f, max_norm / (tn + 1e-6f));
+  if (sqnorm) {
+    // NaN guard on the device (reference: `torch.isnan(fake).any()` before backward, src/models.py:102-105): a NaN/Inf anywhere
+    // in the generator output makes the gradient norm non-finite.  Such a step -- and, through the sticky flag, every later
+    // one -- leaves p, m and v untouched, so the weights the host dumps when it notices are the last finite ones.
+    const double sq = *sqnorm;
+    const bool bad = !(sq == sq) || sq > 1.7e308 || (nonfinite && *nonfinite);
+    if (bad) {
+      if (nonfinite && blockIdx.x == 0 && threadIdx.x == 0) *nonfinite = 1;
+      return;
+    }
+    if (max_norm > 0.f) {
+      const float tn = (float)sqrt(sq);
+      coef = fminf(1.f, max_norm / (tn + 1e-6f));
+    }
   }
   const float step = lr / bc1, isb2 = rsqrtf(bc2);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -110,11 +121,11 @@ MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t
 
 MVIT_API int mvit_adam_clip_step(float* p, const float* g, float* m, float* v, const double* sqnorm, long long n, float lr,
                                  float beta1, float beta2, float eps, float bias_c1, float bias_c2, float max_norm,
-                                 mvit_stream_t stream) {
+                                 int* nonfinite_flag, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (n <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sqnorm, n, lr,
-                     beta1, beta2, eps, bias_c1, bias_c2, max_norm);
+                     beta1, beta2, eps, bias_c1, bias_c2, max_norm, nonfinite_flag);
   return MVIT_LAUNCH_CHECK();
 }
 

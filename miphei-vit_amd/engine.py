@@ -51,10 +51,18 @@ def swiglu_pack_index(hidden):
 class HipEngine:
     def __init__(self, model):
         self.model = model
+        self._flat = None
+        self._opt_stash = None       # Adam state carried across re-flattening (see invalidate)
+        self._nonfinite = None       # device int32: sticky NaN-guard flag written by the Adam kernel
         self.invalidate()
 
     # ------------------------------------------------------------------ state management
     def invalidate(self):
+        """Drop everything derived from the module's tensors (``.to()`` / ``load_state_dict`` / ``set_input_size`` replace
+        or change them).  The optimiser state is NOT derived from them: Adam's moments and step count are stashed, keyed by
+        the flat layout, and put back when the flat buffer is rebuilt (torch.optim state survives those calls too)."""
+        if self._flat is not None and self._flat.m is not None:
+            self._opt_stash = self.optimizer_state_dict()
         self._frozen = None
         self._flat = None
         self._ws = {}
@@ -151,6 +159,11 @@ class HipEngine:
             p.grad = gview[id(p)] if p.requires_grad else None
             o += k
         f = NS(flat=flat, gflat=gflat, n=n, n_lora=n_lora, params=groups, m=None, v=None, step=0, gview=gview)
+        names = {id(p): k for k, p in self.model.named_parameters()}
+        f.layout = [(names.get(id(p), f"param{i}"), p.numel()) for i, p in enumerate(groups)]
+        if self._opt_stash is not None:
+            self._restore_optimizer(f, self._opt_stash)
+            self._opt_stash = None
         NH = c.NH
 
         def hv(buf, name, shape):
@@ -608,8 +621,11 @@ class HipEngine:
         ops.gemm_tn(src, dpre, w.dWt[i], M=Mo, I=K9, J=cout, ldb=cout, ldci=cout, msplit=ms,
                     conv=(r_in, r_in, cin_pad, ld, r_out, r_out, stride))
 
-    def backward(self, dY, on_decoder_done=None):
-        """Gradients of every trainable parameter into the flat gradient buffer (views = param.grad)."""
+    def backward(self, dY, on_decoder_done=None, on_lora_block_done=None):
+        """Gradients of every trainable parameter into the flat gradient buffer (views = param.grad).
+
+        on_decoder_done() is called when the decoder gradients are complete, on_lora_block_done(l) when block l's LoRA
+        gradients are (l descending): hooks of the data-parallel exchange, which all-reduces finished slices meanwhile."""
         sv = self._saved
         if sv is None:
             raise RuntimeError("backward() needs a preceding forward(train=True)")
@@ -700,10 +716,14 @@ class HipEngine:
         if on_decoder_done is not None:
             on_decoder_done()
         # ---- encoder (LoRA gradients; frozen weights need dgrad only)
-        self._encoder_bwd(w, pk, fl, fz)
+        self._encoder_bwd(w, pk, fl, fz, on_block_done=on_lora_block_done)
         return fl.gflat
 
-    def _encoder_bwd(self, w, pk, fl, fz, from_tokens=True, inject=None):
+    def lora_blocks(self):
+        c = self._config()
+        return c.L if c.lora else 0
+
+    def _encoder_bwd(self, w, pk, fl, fz, from_tokens=True, inject=None, on_block_done=None):
         """Backward of the ViT blocks.  from_tokens: start from the gradient of the final-norm tokens in w.dtok (MIPHEI-ViT);
         otherwise the caller has put the gradient of the last block's output into w.dx (f32).  inject(l) is called when w.dx
         holds the gradient of block l's output coming from later blocks and may add to it (forward_intermediates taps)."""
@@ -736,14 +756,16 @@ class HipEngine:
                         c2=fl.dBv[l], isplit=r_, j1=D, jlo2=2 * D)
             ops.gemm_tn(w.dt, w.h1[l], fl.dAq[l], M=M, I=2 * r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit,
                         c2=fl.dAv[l], isplit=r_)
+            if c.alpha != 1.0:       # B2 carries alpha*B: d(B) = alpha * d(alpha*B); scaled before the slice may be exchanged
+                fl.dBq[l].mul_(c.alpha)
+                fl.dBv[l].mul_(c.alpha)
+            if on_block_done is not None:
+                on_block_done(l)
             if l > 0:
                 ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
                 if inject is not None:
                     inject(l - 1)
                 ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)
-        if c.alpha != 1.0:
-            fl.dBq.mul_(c.alpha)
-            fl.dBv.mul_(c.alpha)
 
     # ------------------------------------------------------------------ fused training step
     def loss_and_grad(self, out, target, marker_weights, lambda_factor):
@@ -762,9 +784,47 @@ class HipEngine:
         w.sqn.zero_()
         ops.sqnorm(fl.gflat, w.sqn)
         ops.adam_clip_step(fl.flat, fl.gflat, fl.m, fl.v, w.sqn, float(lr), betas[0], betas[1], eps,
-                           1.0 - betas[0] ** fl.step, 1.0 - betas[1] ** fl.step, float(max_norm))
+                           1.0 - betas[0] ** fl.step, 1.0 - betas[1] ** fl.step, float(max_norm),
+                           nonfinite=self.nonfinite_flag())
         self._pack_key = None  # parameters changed in place through the flat buffer
         return w.sqn
+
+    def nonfinite_flag(self):
+        """Device int32 scalar the Adam kernel sets (and then honours: no further updates) when a gradient norm is NaN/Inf."""
+        dev = self._require_gpu()
+        if self._nonfinite is None or self._nonfinite.device != dev:
+            self._nonfinite = torch.zeros(1, device=dev, dtype=torch.int32)
+        return self._nonfinite
+
+    # ------------------------------------------------------------------ optimiser state (checkpoint / resume)
+    def optimizer_state_dict(self):
+        """Adam state of the fused step: {"step", "exp_avg", "exp_avg_sq", "layout"}; the moments are flat f32 tensors in the
+        order ``layout`` = [(parameter name, numel)] gives (reference: the optimizer state Lightning checkpoints carry)."""
+        fl = self._flat
+        if fl is None or fl.m is None:
+            return self._opt_stash if (fl is None and self._opt_stash is not None) else {"step": 0, "exp_avg": None,
+                                                                                         "exp_avg_sq": None, "layout": None}
+        return {"step": int(fl.step), "exp_avg": fl.m.detach().clone(), "exp_avg_sq": fl.v.detach().clone(),
+                "layout": [tuple(x) for x in fl.layout]}
+
+    def load_optimizer_state_dict(self, sd):
+        if sd is None or sd.get("exp_avg") is None:
+            return
+        if self._flat is None:
+            self._opt_stash = sd          # applied when the flat buffer is built
+        else:
+            self._restore_optimizer(self._flat, sd)
+
+    @staticmethod
+    def _restore_optimizer(f, sd):
+        if sd.get("exp_avg") is None:
+            return
+        if [tuple(x) for x in sd["layout"]] != [tuple(x) for x in f.layout]:
+            raise RuntimeError("optimizer state does not match the trainable parameters of this generator "
+                               f"({len(sd['layout'])} vs {len(f.layout)} tensors in the flat layout)")
+        f.m = sd["exp_avg"].to(device=f.flat.device, dtype=torch.float32).clone()
+        f.v = sd["exp_avg_sq"].to(device=f.flat.device, dtype=torch.float32).clone()
+        f.step = int(sd["step"])
 
     def grad_buckets(self):
         """(decoder gradients, LoRA gradients): contiguous slices of the flat gradient buffer for all-reduce."""

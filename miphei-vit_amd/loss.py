@@ -27,3 +27,12 @@ def marker_weights_from_stats(stds):
     """weights = (1/std) / min(1/std)   (reference ``src/train.py:137-140``)."""
     inv = 1.0 / torch.as_tensor(stds, dtype=torch.float64)
     return (inv / inv.min()).float()
+
+
+def marker_weights_from_file(path, channel_names):
+    """Per-marker weights from a ``channel_stats.json``-shaped file ({name: {"std": ...}}), as ``src/train.py:137-142``
+    builds them.  A missing marker is a ``KeyError`` naming it (the reference fails the same way)."""
+    import json
+    with open(path) as f:
+        stats = json.load(f)
+    return marker_weights_from_stats([stats[n]["std"] for n in channel_names])

@@ -9,7 +9,10 @@ Mirrors the constructor and step methods of the reference LightningModule (``/ro
 The non-GAN ``training_step`` runs as ONE fused device sequence: HIP generator forward -> fused WeightedMSE loss +
 gradient -> HIP backward -> (optional) RCCL all-reduce of the two gradient buckets, the decoder bucket overlapped
 with the encoder backward -> global-norm clip + Adam on the flat parameter buffer -> LR schedule.  The reference's
-per-step host sync (``torch.isnan(fake).any()``, models.py:102-105) becomes an asynchronous check of the loss scalar.
+per-step host sync (``torch.isnan(fake).any()``, models.py:102-105) becomes a device-side gate plus an asynchronous host
+check: the Adam kernel skips the update (and every later one) when the gradient norm is non-finite and raises a sticky
+device flag; the host copies that flag out without blocking after every step, inspects the copies that have landed and
+then saves ``weights_nan.ckpt`` -- still the last finite weights -- and raises ``ValueError("Nan found")``.
 """
 from __future__ import annotations
 
@@ -51,8 +54,8 @@ class ModelModule(_Base):
         # fused-step state
         self.total_iters = None
         self.global_step_ = 0
-        self.nan_check_every = 50
-        self._pending_loss = None
+        self.nan_check = True         # asynchronous host side of the NaN guard (the device side is always on)
+        self._pending = []            # (event, pinned host int32) copies of the device NaN flag, oldest first
         self.grad_sync = None  # set by trainer.DataParallelSync for multi-GPU runs
         self.last_loss = None
         # PSNR / SSIM collections of the reference (models.py:35-52), device-resident state, updated after every step
@@ -109,7 +112,8 @@ class ModelModule(_Base):
             w = self.loss_reconstruct.marker_weights
         loss, dY = eng.loss_and_grad(out, y.to(out.device), w, self.loss_reconstruct.lambda_factor)
         sync = self.grad_sync
-        eng.backward(dY, on_decoder_done=(sync.decoder_ready if sync is not None else None))
+        eng.backward(dY, on_decoder_done=(sync.decoder_ready if sync is not None else None),
+                     on_lora_block_done=(sync.lora_block_done if sync is not None else None))
         if sync is not None:
             sync.finish()
         eng.adam_step(self.current_lr(), betas=(0.5, 0.999), eps=1e-7, max_norm=1.0)
@@ -153,21 +157,58 @@ class ModelModule(_Base):
         self.train_pix_metrics.reset()
         return vals
 
-    def _nan_guard(self, loss):
-        """Asynchronous form of the reference's NaN guard: a NaN/Inf anywhere in the generator output makes the loss
-        non-finite; the device scalar is copied out without blocking and inspected ``nan_check_every`` steps later."""
-        if self.global_step_ % self.nan_check_every == 0:
-            if self._pending_loss is not None:
-                ev, host = self._pending_loss
-                ev.synchronize()
-                if not math.isfinite(float(host)):
-                    torch.save(self.state_dict(), "weights_nan.ckpt")
-                    raise ValueError("Nan found")
-            host = torch.empty(1, dtype=torch.float64, pin_memory=True)
-            host.copy_(loss.detach(), non_blocking=True)
+    def _nan_guard(self, loss=None, flush=False):
+        """Host side of the NaN guard (reference models.py:102-105).  The Adam kernel has already refused the update on the
+        device if the step was non-finite; here the sticky device flag is copied to pinned memory behind the step (no sync) and
+        every copy that has completed is inspected.  ``flush=True`` waits for the outstanding ones (end of training)."""
+        eng = getattr(self.generator, "_engine", None)
+        flag = eng.nonfinite_flag() if (self.nan_check and eng is not None and hasattr(eng, "nonfinite_flag")) else None
+        if flag is not None and not flush:
+            host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._pending_loss = (ev, host)
+            self._pending.append((ev, host))
+        while self._pending and (flush or self._pending[0][0].query() or len(self._pending) > 8):
+            ev, host = self._pending.pop(0)
+            ev.synchronize()
+            if int(host) != 0:
+                self._pending = []
+                torch.save(self.checkpoint_state(), "weights_nan.ckpt")   # the update was gated: last finite weights
+                raise ValueError("Nan found")
+        if flag is None and loss is not None and self.nan_check:   # generators without the fused step: the reference's sync check
+            if not bool(torch.isfinite(loss)):
+                torch.save(self.state_dict(), "weights_nan.ckpt")
+                raise ValueError("Nan found")
+
+    def on_train_end(self):
+        self._nan_guard(flush=True)
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def checkpoint_state(self):
+        """Lightning-shaped checkpoint of the fused trainer: ``state_dict`` with the reference prefixes (``generator.<key>``,
+        ``loss_reconstruct.marker_weights``; ``/root/reference/src/inference.py:79-84`` strips them), plus what resuming needs
+        and the reference's Lightning checkpoints carry: Adam moments + step count, the LR-schedule position and horizon.
+        BatchNorm running statistics are this rank's (data-parallel replicas keep local statistics, as vanilla DDP does)."""
+        eng = getattr(self.generator, "_engine", None)
+        opt = eng.optimizer_state_dict() if eng is not None and hasattr(eng, "optimizer_state_dict") else None
+        if opt is not None and opt.get("exp_avg") is not None:
+            opt = dict(opt, exp_avg=opt["exp_avg"].cpu(), exp_avg_sq=opt["exp_avg_sq"].cpu())
+        return {"state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()
+                               if k.startswith("generator.") or k.startswith("loss_reconstruct.")},
+                "optimizer_state": opt, "global_step": int(self.global_step_), "total_iters": self.total_iters,
+                "lr_g": float(self.lr_g), "bn_running_stats": "rank-local"}
+
+    def load_checkpoint_state(self, ckpt):
+        sd = {k[len("generator."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("generator.")}
+        self.generator.load_state_dict(sd)
+        self.global_step_ = int(ckpt.get("global_step", 0))
+        if ckpt.get("total_iters") is not None:
+            self.total_iters = ckpt["total_iters"]
+        eng = getattr(self.generator, "_engine", None)
+        if eng is not None and hasattr(eng, "load_optimizer_state_dict"):
+            eng.load_optimizer_state_dict(ckpt.get("optimizer_state"))
+        return self
 
     def _evaluation_step(self, batch, metrics):
         self.generator.eval()

@@ -290,8 +290,12 @@ def sqnorm(x, out):
     _call("mvit_sqnorm", _p(x), _p(out), x.numel())
 
 
-def adam_clip_step(p, g, m, v, sqn, lr, beta1, beta2, eps, bc1, bc2, max_norm):
-    _call("mvit_adam_clip_step", _p(p), _p(g), _p(m), _p(v), _p(sqn), p.numel(), lr, beta1, beta2, eps, bc1, bc2, max_norm)
+def adam_clip_step(p, g, m, v, sqn, lr, beta1, beta2, eps, bc1, bc2, max_norm, nonfinite=None):
+    """nonfinite: device int32 scalar; set (sticky) and the update skipped when the gradient norm is NaN/Inf."""
+    if nonfinite is not None:
+        assert nonfinite.dtype == torch.int32
+    _call("mvit_adam_clip_step", _p(p), _p(g), _p(m), _p(v), _p(sqn), p.numel(), lr, beta1, beta2, eps, bc1, bc2, max_norm,
+          _p(nonfinite))
 
 
 def u8_nhwc_to_f32_nchw(src, dst, scale, shift):

@@ -3,8 +3,10 @@ single-device, ``Trainer(accelerator='gpu', devices=1)`` at /root/reference/src/
 
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU tests).
 Tiles are independent, so the minibatch shards across ranks; the only exchange is the all-reduce of the flat
-gradient buffer (6.7 M f32 for H-Optimus-0 + LoRA), split into two buckets: the decoder bucket is launched as soon
-as the decoder backward has finished and overlaps the encoder backward on RCCL's own stream, the LoRA bucket follows.
+gradient buffer (6.7 M f32 for H-Optimus-0 + LoRA), split into buckets issued in reverse-forward order while the
+backward pass runs: the decoder bucket as soon as the decoder backward has finished, then the LoRA gradients in
+sub-buckets of ten blocks as the encoder backward walks from block 39 to block 0 (RCCL's own stream; only the last
+sub-bucket can be exposed).
 """
 from __future__ import annotations
 
@@ -13,13 +15,26 @@ import torch.distributed as dist
 
 
 class DataParallelSync:
-    """Averages the flat gradient buffer over ranks; ``decoder_ready`` is called from inside ``engine.backward``."""
+    """Averages the flat gradient buffer over ranks while the backward pass is still running.
 
-    def __init__(self, engine, group=None, force=False):
+    Buckets are contiguous slices of the flat gradient buffer, issued in the order the backward pass completes them
+    (reverse-forward): the decoder bucket (``decoder_ready``, called from ``engine.backward`` when the
+    decoder backward has finished, i.e. before the first encoder block) and ``lora_buckets`` sub-buckets of the LoRA
+    gradients -- the flat layout is per block, so blocks ``hi..lo`` are one slice -- each issued by ``lora_block_done(l)``
+    as soon as block ``lo`` of its range has produced its dA/dB.  Every all-reduce runs on the backend's own stream
+    (RCCL's on ROCm), so only the last sub-bucket (``n_lora / lora_buckets`` floats; < 2 MB for H-Optimus-0 with 4) can be
+    exposed.  ``finish`` waits for all of them on the compute stream and applies the 1/world average; with ``timing`` on it
+    brackets that wait with events: the time the compute stream was held back by communication."""
+
+    def __init__(self, engine, group=None, force=False, lora_buckets=4, timing=False):
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path on one rank
-        self._work = None
+        self.lora_buckets = max(1, int(lora_buckets))
+        self.timing = timing
+        self.exposed_events = []
+        self._work = []
+        self._ranges = None
 
     def broadcast_parameters(self, src=0):
         if self.active:
@@ -27,22 +42,57 @@ class DataParallelSync:
             dist.broadcast(fl.flat, src=src, group=self.group)
             self.engine._pack_key = None
 
+    def _issue(self, t):
+        if t.numel():
+            self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def decoder_ready(self):
         if self.active:
             dec, _ = self.engine.grad_buckets()
-            self._work = dist.all_reduce(dec, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._issue(dec)
+
+    def _lora_ranges(self):
+        """{lowest block of a sub-bucket: slice of the LoRA gradient region}; blocks are contiguous in the flat layout."""
+        if self._ranges is None:
+            _, lora = self.engine.grad_buckets()
+            L = self.engine.lora_blocks()
+            per = lora.numel() // L if L else 0
+            nb = min(self.lora_buckets, L) if L else 0
+            edges = [round(i * L / nb) for i in range(nb + 1)] if nb else []
+            self._ranges = {edges[i]: (edges[i] * per, edges[i + 1] * per) for i in range(nb)}
+        return self._ranges
+
+    def lora_block_done(self, l):
+        """Called by ``engine._encoder_bwd`` after block ``l`` (descending) has written its LoRA gradients."""
+        if self.active:
+            r = self._lora_ranges().get(l)
+            if r is not None:
+                _, lora = self.engine.grad_buckets()
+                self._issue(lora[r[0]:r[1]])
 
     def finish(self):
-        if self.active:
-            dec, lora = self.engine.grad_buckets()
-            w2 = dist.all_reduce(lora, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if lora.numel() else None
-            if self._work is not None:
-                self._work.wait()
-                self._work = None
-            if w2 is not None:
-                w2.wait()
-            if self.world > 1:
-                self.engine._flat.gflat.mul_(1.0 / self.world)
+        if not self.active:
+            return
+        if self.timing:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for wk in self._work:
+            wk.wait()
+        self._work = []
+        if self.world > 1:
+            self.engine._ensure_flat().gflat.mul_(1.0 / self.world)
+        if self.timing:
+            e1.record()
+            self.exposed_events.append((e0, e1))
+
+    def exposed_ms(self):
+        """Mean per-step time the compute stream waited in ``finish`` (all-reduce tail + the 1/world scale)."""
+        if not self.exposed_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.exposed_events]
+        self.exposed_events = []
+        return sum(ms) / len(ms)
 
 
 def allreduce_mean_(flat, world, group=None):

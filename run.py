@@ -7,7 +7,6 @@ Mirrors ``/root/reference/run.py`` + ``src/train.py:34-210`` for the parts on th
 build generator / loss / ``ModelModule``, run the (fused) training steps, save ``model.safetensors`` (LoRA + decoder) with
 the reference key names.  Data loading is outside the path: tiles are synthetic and generated on the device.
 """
-import json
 import os
 import sys
 import time
@@ -24,7 +23,7 @@ def main(argv):
     from miphei_vit_amd.checkpoint import save_pruned_safetensors
     from miphei_vit_amd.config import compose
     from miphei_vit_amd.generators import get_generator
-    from miphei_vit_amd.loss import WeightedMSELoss, marker_weights_from_stats
+    from miphei_vit_amd.loss import WeightedMSELoss, marker_weights_from_file
     from miphei_vit_amd.models import ModelModule
     from miphei_vit_amd.trainer import DataParallelSync
 
@@ -41,12 +40,10 @@ def main(argv):
         generator = get_generator(cfg.model.model_name, S, 3, nc, cfg)
     if not cfg.model.encoder.get("pretrained", True) and cfg.model.encoder.encoder_weights is None:
         synthetic_init_(generator, seed=0)
-    if cfg.data.channel_stats_path:
-        stats = json.load(open(cfg.data.channel_stats_path))
-        weights = marker_weights_from_stats([stats[n]["std"] for n in cfg.data.targ_channel_names])
-    else:
-        from oracle.model import ORION_MARKER_WEIGHTS  # constants only (train.py:137-140 on the ORION channel_stats.json)
-        weights = torch.tensor(ORION_MARKER_WEIGHTS[:nc])
+    stats_path = cfg.data.channel_stats_path or "configs/channel_stats_orion.json"
+    if not os.path.isabs(stats_path):
+        stats_path = os.path.join(ROOT, stats_path)
+    weights = marker_weights_from_file(stats_path, cfg.data.targ_channel_names)   # train.py:137-142
     loss = WeightedMSELoss(cfg.train.losses.lambda_factor, weights)
     module = ModelModule(generator, None, cfg.train.learning_rate_g * B ** 0.5, cfg.train.learning_rate_d, loss,
                          gan_train=cfg.train.gan_train).to(dev)
@@ -56,18 +53,32 @@ def main(argv):
         sync = DataParallelSync(generator._engine)
         sync.broadcast_parameters(0)
         module.grad_sync = sync
+    logdir = os.path.join(ROOT, "logs")
+    os.makedirs(logdir, exist_ok=True)
+    start = 0
+    resume = cfg.train.get("resume_from")
+    if resume:      # ++train.resume_from=logs/last.ckpt : weights, Adam moments + step count, LR-schedule position
+        module.load_checkpoint_state(torch.load(resume, map_location="cpu", weights_only=False))
+        start = module.global_step_
+        if rank == 0:
+            print(f"resumed from {resume} at step {start}", flush=True)
+    every = int(cfg.train.get("checkpoint_every") or 0)
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(start, steps):
         x, y = synthetic_batch(1234 + rank * 1000 + i, B, S, nc, dev)
         out = module.training_step({"image": x, "target": y}, i)
         if rank == 0 and (i % 10 == 0 or i == steps - 1):
             print(f"step {i:5d}  loss {float(out):.4f}  lr {module.current_lr(i):.3e}", flush=True)
+        if rank == 0 and every and (i + 1) % every == 0 and i + 1 < steps:
+            # rank 0's replica: parameters are identical on all ranks, BatchNorm running statistics are rank-local (noted in
+            # the file as "bn_running_stats": "rank-local")
+            torch.save(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
+    module.on_train_end()           # drains the asynchronous NaN guard
     torch.cuda.synchronize()
     if rank == 0:
         dt = time.perf_counter() - t0
-        print(f"{steps} steps, {world * B * steps / dt:.1f} tiles/s")
-        logdir = os.path.join(ROOT, "logs")
-        os.makedirs(logdir, exist_ok=True)
+        print(f"{steps - start} steps, {world * B * (steps - start) / dt:.1f} tiles/s")
+        torch.save(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
         save_pruned_safetensors(generator, os.path.join(logdir, "model.safetensors"))
         print("saved", os.path.join(logdir, "model.safetensors"))
     if dist.is_initialized():

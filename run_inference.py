@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--batch_size", type=int, default=64)
     ap.add_argument("--num_batches", type=int, default=2)
     ap.add_argument("--output_dir", default=None)
+    ap.add_argument("--allow-random-encoder", action="store_true",
+                    help="run with RANDOM weights of the frozen encoder architecture when model.encoder.encoder_weights is null "
+                         "(benchmarking / smoke runs only: the predictions are meaningless)")
     a, overrides = ap.parse_known_args()
     from miphei_vit_amd.checkpoint import load_generator_checkpoint
     from miphei_vit_amd.config import compose
@@ -37,7 +40,16 @@ def main():
     with torch.device(dev):
         gen = get_generator(cfg.model.model_name, S, 3, nc, cfg)
     if cfg.model.encoder.encoder_weights is None:
-        synthetic_init_(gen, seed=0)      # frozen encoder: random weights of the architecture (no network here)
+        # The checkpoint directory holds LoRA + decoder keys only; the frozen foundation encoder comes from
+        # model.encoder.encoder_weights.  The reference downloads H-Optimus-0 or fails (foundation_models.py:59-66); there is no
+        # network here, so without weights this refuses unless explicitly told to produce numbers for timing.
+        if not (a.allow_random_encoder or os.environ.get("MIPHEI_RANDOM_INIT") == "1"):
+            raise SystemExit("model.encoder.encoder_weights is null: the frozen encoder has no weights to load.  Pass "
+                             "++model.encoder.encoder_weights=/path/to/hoptimus0.safetensors, or --allow-random-encoder "
+                             "(MIPHEI_RANDOM_INIT=1) for a timing run whose predictions are meaningless.")
+        print("WARNING: frozen encoder initialised with RANDOM weights (--allow-random-encoder): predictions are meaningless",
+              file=sys.stderr, flush=True)
+        synthetic_init_(gen, seed=0)
     load_generator_checkpoint(gen, a.checkpoint_dir)
     gen.eval()
     run, x_static, out_static = gen._engine.capture_inference(a.batch_size)

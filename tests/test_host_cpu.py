@@ -178,40 +178,37 @@ def test_pos_embed_resize_on_load():
     assert out["pos_embed"].shape == (1, 18 * 18, 96)
 
 
-def test_config_compose_overlays_and_overrides():
-    from miphei_vit_amd.config import compose
-    cfg = compose(os.path.join(ROOT, "configs"), ["+default_configs=miphei-vit", "++train.epochs=100", "train.batch_size=8",
-                                                  "++model.encoder.encoder_weights=null"])
-    assert cfg.model.model_name == "myvitmatte" and cfg.model.encoder.encoder_name == "hoptimus0"
-    assert cfg.train.epochs == 100 and cfg.train.batch_size == 8 and cfg.train.gan_train is False
-    assert cfg.train.losses.lambda_factor == 50 and len(cfg.data.targ_channel_names) == 16
-    assert cfg.model.encoder.encoder_weights is None and cfg.get_path("model.encoder.pretrained") is False
-    tiny = compose(os.path.join(ROOT, "configs"), ["+default_configs=tiny"])
-    assert tiny.model.encoder.encoder_name == "tiny" and len(tiny.data.targ_channel_names) == 3
-
-
 _DDP_WORKER = r'''
 import os, sys, types, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from miphei_vit_amd.trainer import DataParallelSync
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-n, n_lora = 1000, 300
-class FakeEngine:                      # the exchange only touches the flat buffers and the two bucket slices
+n, n_lora, L = 1000, 300, 10
+class FakeEngine:                      # the exchange only touches the flat buffers and the bucket slices
     def __init__(self):
         g = torch.Generator().manual_seed(100 + rank)
         self._flat = types.SimpleNamespace(flat=torch.full((n,), float(rank)), gflat=torch.randn(n, generator=g), n_lora=n_lora)
         self._pack_key = "x"
     def _ensure_flat(self): return self._flat
     def grad_buckets(self): return self._flat.gflat[n_lora:], self._flat.gflat[:n_lora]
+    def lora_blocks(self): return L
 eng = FakeEngine()
 ref = torch.stack([torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]).mean(0)
-sync = DataParallelSync(eng)
-sync.broadcast_parameters(0)
-assert torch.equal(eng._flat.flat, torch.zeros(n)) and eng._pack_key is None      # rank 0's parameters everywhere
-sync.decoder_ready()        # launched from inside backward once the decoder gradients exist
-sync.finish()               # LoRA bucket + wait + average
-assert torch.allclose(eng._flat.gflat, ref, atol=1e-6)
+for nb in (4, 1, 3, 64):
+    eng = FakeEngine()
+    sync = DataParallelSync(eng, lora_buckets=nb)
+    sync.broadcast_parameters(0)
+    assert torch.equal(eng._flat.flat, torch.zeros(n)) and eng._pack_key is None      # rank 0's parameters everywhere
+    sync.decoder_ready()        # launched from inside backward once the decoder gradients exist
+    issued = []
+    for l in range(L - 1, -1, -1):  # encoder backward, block 39 -> 0: a sub-bucket goes out when its lowest block is done
+        before = len(sync._work)
+        sync.lora_block_done(l)
+        if len(sync._work) > before: issued.append(l)
+    assert len(issued) == min(nb, L) and issued[-1] == 0 and issued == sorted(issued, reverse=True), issued
+    sync.finish()               # wait for every bucket + average
+    assert torch.allclose(eng._flat.gflat, ref, atol=1e-6), nb
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -224,3 +221,28 @@ def test_gloo_world2_data_parallel_sync(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_bench_self_launch_dry_gloo_world2():
+    """`python bench.py --gpus 2` from a plain shell: the parent spawns torch.distributed.run as a child (it must never
+    touch the GPU), the ranks rendezvous on 127.0.0.1, run the bucketed exchange protocol and rank 0 prints ONE JSON line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo", "--steps",
+                        "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["dry"] and r["exchange_ok"] and r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["steps"] == 3
+    # a failing child is reported through the exit code, not swallowed
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--backend", "nccl", "--steps",
+                        "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not p.stdout.strip()
+
+
+def test_bench_parent_does_not_touch_the_gpu_before_launching():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main("):]
+    assert main.index("self_launch(a, argv)") < main.index("torch.cuda.")
+    assert "os.exec" not in src and "execv" not in src

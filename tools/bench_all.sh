@@ -1,0 +1,31 @@
+#!/bin/bash
+# Measurement pass on the GPU box: every bench line DESIGN.md quotes, the rocprofv3 kernel statistics and the two PMC passes of
+# the headline command.  Writes gpurun_out/<tag>/ (scratch) and, with COPY=1 (default), the summaries into profiles/<round>_*.
+#   gpurun --timeout 1500 -- 'bash tools/bench_all.sh r02'
+# Every line is produced by bench.py itself (one JSON object per file), so a claim in DESIGN.md can be re-run verbatim.
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O profiles
+run() { out=$1; shift; python3 bench.py "$@" > $O/$out.json 2> $O/$out.err || echo "FAILED: $out" >&2; }
+run bench_train                                                                    # BASELINE configs[1], the driver's command
+run bench_train_metrics_on --metrics 1 --no-cpu-baseline
+run bench_infer_b64_hipgraph --mode infer --batch 64 --steps 20 --warmup 5         # configs[4]: tiles/s + p50 batch latency
+run bench_train_512_b4 --img 512 --batch 4 --steps 10 --warmup 3 --no-cpu-baseline # configs[3], 1 GPU
+run bench_embed_b64 --mode embed --batch 64 --steps 20 --warmup 5
+run bench_unetr_train --generator unet_lora --no-cpu-baseline --steps 10 --warmup 3
+run bench_unetr_infer_b64 --generator unet_lora --mode infer --batch 64 --steps 10 --warmup 3
+MIPHEI_FORCE_DDP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 \
+    > $O/bench_train_rccl_1rank.json 2> $O/bench_train_rccl_1rank.err              # the bucketed exchange on one rank
+rocprofv3 --kernel-trace --stats -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+db=$(ls $O/stats/*/*.db 2>/dev/null | head -1)
+[ -n "$db" ] && python3 tools/prof_summary.py $db 70 > $O/kernel_stats_train.txt
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > $O/pmc_traffic.txt
+if [ "${COPY:-1}" = 1 ]; then
+  for f in $O/bench_*.json $O/kernel_stats_train.txt $O/pmc_traffic.json; do
+    [ -s "$f" ] && cp $f profiles/${R}_$(basename $f)
+  done
+fi
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write      # raw traces are large; the summaries above are what is kept
+for f in $O/bench_*.json; do echo "== $f"; cut -c1-400 $f; done; head -25 $O/kernel_stats_train.txt; cat $O/pmc_traffic.txt

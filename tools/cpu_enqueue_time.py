@@ -13,7 +13,7 @@ with torch.device(dev):
     model = get_vitmatte("hoptimus0", 256, 16, use_lora=True, pretrained=False)
 bench.synthetic_init_(model, seed=0)
 mod = ModelModule(model, None, 8e-4, 0.0, WeightedMSELoss(50.0, torch.ones(16))).to(dev)
-mod.total_iters, mod.nan_check_every, mod.update_pix_metrics = 100000, 10 ** 9, False
+mod.total_iters, mod.update_pix_metrics = 100000, False
 x, y = bench.synthetic_batch(1, 16, 256, 16, dev)
 for i in range(4):
     mod.training_step({"image": x, "target": y}, i)

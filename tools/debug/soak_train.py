@@ -1,5 +1,5 @@
 """Soak run: N fused training steps of the full configuration on a fixed set of synthetic batches with the asynchronous NaN guard
-active (nan_check_every = 50); prints the loss every 50 steps and the sustained rate."""
+active; prints the loss every 50 steps and the sustained rate."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -16,7 +16,6 @@ with torch.device(dev):
 bench.synthetic_init_(model, seed=0)
 mod = ModelModule(model, None, 2e-4 * 4, 0., WeightedMSELoss(50.0, orion_marker_weights(16))).to(dev)
 mod.total_iters = 2000
-mod.nan_check_every = 50
 batches = [bench.synthetic_batch(100 + i, 16, 256, 16, dev) for i in range(8)]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
