@@ -96,6 +96,12 @@ MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_stream_t stre
  * src/generators/foundation_models.py:53-57 and Encoder.forward src/generators/mipheivit.py:154. */
 MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, void* out_bf16, int M, int D, float eps,
                                 mvit_stream_t stream);
+/* LayerNorm forward fused with the LoRA down-projection of the block's qkv adapter: out = bf16(LN(x)) as above and
+ * t[M,R2] = out @ AcatT^T (bf16, f32 accumulate), AcatT [R2, D] = rows of [A_q | A_v]^T, R2 = 2*rank <= 16.
+ * Replaces `self.lora_q.A` / `self.lora_v.A` products of QkvWithLoRA.forward (src/generators/lora.py:16-18,29-33) on the LN1
+ * output of timm Block.forward. */
+MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float* b, void* out, const void* AcatT, void* t,
+                                     int M, int D, float eps, int R2, mvit_stream_t stream);
 /* dx (+)= dLN/dx(dh); statistics recomputed from x.  If gamma_next/dy are given also writes
  * dy(bf16) = gamma_next * dx_total (the LayerScale-scaled gradient of the preceding residual branch). */
 MVIT_API int mvit_layernorm_bwd(const void* dh_bf16, const float* x, const float* w, float* dx, const float* gamma_next,
@@ -209,6 +215,17 @@ MVIT_API long long mvit_pix_metrics_scratch_bytes(int B);
 MVIT_API int mvit_pix_metrics_update(const float* pred, const float* target, double* state /*[4]*/, double* scratch,
                                      long long scratch_bytes, int B, int C, int H, int W, float lo, float hi,
                                      mvit_stream_t stream);
+
+/* ---------------------------------------------------------------- per-step operand packs of the trainable tensors */
+/* LoRA adapters (src/generators/lora.py:8-33) from the flat f32 parameter region `lora` = L x [Aq [D,r] | Bq [r,D] | Av | Bv]
+ * to the bf16 operands of the kernels, R2 = 2r: AcatT [L,R2,D], Acat [L,D,R2] (may be NULL), B2 [L,3D,R2] (alpha*B on the q
+ * rows / v rows, zero elsewhere: the K-extension of the qkv GEMM), Bqv [L,2,r,D] = alpha*Bq, alpha*Bv (may be NULL). */
+MVIT_API int mvit_lora_pack(const float* lora, void* AcatT, void* Acat, void* B2, void* Bqv, int L, int D, int r, float alpha,
+                            mvit_stream_t stream);
+/* Weight gradient of a 3x3 convolution from the TN-GEMM layout dWt [(ky,kx,c_pad), Cout] f32 to nn.Conv2d's [Cout,Cin,3,3]
+ * (inverse of mvit_pack_conv3x3_weights incl. its channel rotation); accumulate != 0 adds to dW. */
+MVIT_API int mvit_unpack_conv3x3_wgrad(const float* dWt, float* dW, int Cout, int Cin, int Cp, int rot, int accumulate,
+                                       mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- loss / optimiser */
 /* WeightedMSELoss (src/loss.py:47-57): loss_acc += sum_c w_c sum (p-t)^2 (caller multiplies by lambda/(C*B*HW));

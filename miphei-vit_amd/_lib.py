@@ -45,6 +45,9 @@ SIGNATURES = {
     "mvit_gemm_variant": [C.POINTER(GemmArgs)],
     "mvit_gemm_tn_bf16": [C.POINTER(GemmTnArgs), vp],
     "mvit_layernorm_fwd": [vp, vp, vp, vp, ci, ci, cf, vp],
+    "mvit_layernorm_lora_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
+    "mvit_lora_pack": [vp, vp, vp, vp, vp, ci, ci, ci, cf, vp],
+    "mvit_unpack_conv3x3_wgrad": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
     "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
     "mvit_skinny_xw2": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],

@@ -51,6 +51,102 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------ LayerNorm forward + LoRA down-projection
+// h = LN(x) (bf16) and, from the row while it is still in registers, t = h @ [A_q | A_v]  ([M, R2], R2 = 2*rank <= 16):
+// the LoRA products of QkvWithLoRA (src/generators/lora.py:16-18,29-33) start from the same LN1 output the qkv GEMM reads, so
+// the separate skinny GEMM (one more pass over h, one more launch per block) disappears.  The adapter matrix is staged in
+// LDS as AcatT [R2, D] bf16 (48 KB for D = 1536); each lane multiplies its 4-element groups of the bf16-rounded row with
+// v_dot2c_f32_bf16 (same products as the bf16 MFMA path: bf16 x bf16, f32 accumulate) and the R2 partial sums are
+// reduced across the wave with a halving butterfly (R2/2 + R2/4 + ... exchanges instead of 6 per value).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_v;
+__global__ __launch_bounds__(256) void ln_fwd_lora_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t, int M, int D,
+                                                          float eps, int R2) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  uint2* As = (uint2*)lds_raw;                       // [R2][D/4] groups of 4 bf16
+  const int nv = D >> 2;
+  for (int i = threadIdx.x; i < R2 * nv; i += 256) As[i] = ((const uint2*)AcatT)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float4* xr = (const float4*)(x + (size_t)row * D);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < nv) {
+        v[i] = xr[idx];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < nv) {
+        const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+        q += (a * a + bb * bb) + (c * c + d * d);
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    uint2* o = (uint2*)(out + (size_t)row * D);
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < nv) {
+        const float4 ww = ((const float4*)w)[idx], bv = ((const float4*)b)[idx];
+        uint2 r;
+        r.x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
+        r.y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
+        o[idx] = r;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (j < R2) {
+            const uint2 a = As[j * nv + idx];
+            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&r.x, *(const bf16x2_v*)&a.x, acc[j], false);
+            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&r.y, *(const bf16x2_v*)&a.y, acc[j], false);
+          }
+        }
+      }
+    }
+    // halving butterfly: after the exchange with lane^32 the lower half owns values 0..7 and the upper half 8..15, and so on;
+    // lane L ends up with value index (L >> 2) & 15 summed over its 4-lane group's partners, two more steps finish it
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool up = lane & 32;
+      const float send = up ? acc[j] : acc[j + 8], keep = up ? acc[j + 8] : acc[j];
+      acc[j] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool up = lane & 16;
+      const float send = up ? acc[j] : acc[j + 4], keep = up ? acc[j + 4] : acc[j];
+      acc[j] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool up = lane & 8;
+      const float send = up ? acc[j] : acc[j + 2], keep = up ? acc[j + 2] : acc[j];
+      acc[j] = keep + __shfl_xor(send, 8, 64);
+    }
+    {
+      const bool up = lane & 4;
+      const float send = up ? acc[0] : acc[1], keep = up ? acc[1] : acc[0];
+      acc[0] = keep + __shfl_xor(send, 4, 64);
+    }
+    acc[0] += __shfl_xor(acc[0], 2, 64);
+    acc[0] += __shfl_xor(acc[0], 1, 64);
+    const int j = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    if ((lane & 3) == 0 && j < R2) t[(size_t)row * R2 + j] = f2bf(acc[0]);
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward (input grad only)
 // dx (+)= rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * w.  Statistics are recomputed from x.
 // Optionally emits dy = bf16(gamma_next * dx_total): the LayerScale-scaled gradient the next dgrad GEMM consumes.
@@ -256,6 +352,20 @@ MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, 
   MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)out, M, D, eps);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float* b, void* out, const void* AcatT, void* t,
+                                     int M, int D, float eps, int R2, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV || R2 <= 0 || R2 > 16 || !AcatT || !t) return MVIT_EINVAL;
+  const size_t lds = (size_t)R2 * D * 2;
+  static mvit_per_device_size raised;
+  if (mvit_ensure_dynamic_lds((const void*)ln_fwd_lora_kernel, lds, raised) != MVIT_OK) return MVIT_EINVAL;
+  // persistent blocks (the 48 KB adapter image is loaded once per block): three per CU fit the LDS
+  const int blocks = (M + 3) / 4 < 768 ? (M + 3) / 4 : 768;
+  hipLaunchKernelGGL(ln_fwd_lora_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, w, b, (bf16_t*)out,
+                     (const bf16_t*)AcatT, (bf16_t*)t, M, D, eps, R2);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -274,32 +274,41 @@ class HipEngine:
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
         fl = self._flat
         if c.lora:
-            if fl is not None:
-                Aq, Av, Bq, Bv = fl.Aq, fl.Av, fl.Bq, fl.Bv
-            else:
-                Aq = torch.stack([f32(b.attn.qkv.lora_q.A) for b in vit.blocks])
-                Av = torch.stack([f32(b.attn.qkv.lora_v.A) for b in vit.blocks])
-                Bq = torch.stack([f32(b.attn.qkv.lora_q.B) for b in vit.blocks])
-                Bv = torch.stack([f32(b.attn.qkv.lora_v.B) for b in vit.blocks])
             r, D = c.rank, c.D
-            pk.Acat = torch.cat([Aq, Av], dim=2).contiguous()                      # [L, D, 2r] f32
-            B2 = torch.zeros(c.L, 3 * D, 2 * r, device=dev, dtype=bf)
-            B2[:, :D, :r] = (c.alpha * Bq).transpose(1, 2)
-            B2[:, 2 * D:, r:] = (c.alpha * Bv).transpose(1, 2)
-            pk.B2 = B2                                                              # [L, 3D, 2r] bf16
-            pk.AcatT = pk.Acat.transpose(1, 2).to(bf).contiguous()                 # [L, 2r, D]: B operand of t = h @ A
-            if not need_bwd:
-                # inference: fold the adapters into the packed projection, W' = W + alpha * (A B)^T on the q and v rows
-                # (SURVEY.md section 8f row 1 "LoRA merge"); the rank-2r K extension and the x @ A product disappear
-                pk.wqkv_merged = []
-                for l, blk in enumerate(vit.blocks):
-                    wm = f32(blk.attn.qkv.qkv.weight).clone()
-                    wm[:D] += c.alpha * (Aq[l] @ Bq[l]).t()
-                    wm[2 * D:] += c.alpha * (Av[l] @ Bv[l]).t()
-                    pk.wqkv_merged.append(wm.to(bf).contiguous())
-            if need_bwd:
-                pk.Acat16 = pk.Acat.to(bf)                                          # B2 operand of the dh1 GEMM
-                pk.Bq16, pk.Bv16 = (c.alpha * Bq).to(bf).contiguous(), (c.alpha * Bv).to(bf).contiguous()  # [L, r, D]
+            if fl is not None and need_bwd:
+                # training: every bf16 operand of the adapters from the flat parameter region in ONE launch
+                pk.AcatT = torch.empty(c.L, 2 * r, D, device=dev, dtype=bf)            # [L, 2r, D]: B operand of t = h @ A
+                pk.Acat16 = torch.empty(c.L, D, 2 * r, device=dev, dtype=bf)           # B2 operand of the dh1 GEMM
+                pk.B2 = torch.empty(c.L, 3 * D, 2 * r, device=dev, dtype=bf)           # [L, 3D, 2r]: qkv K-extension
+                bqv = torch.empty(c.L, 2, r, D, device=dev, dtype=bf)                  # alpha * Bq, alpha * Bv
+                ops.lora_pack(fl.flat[:fl.n_lora], pk.AcatT, pk.Acat16, pk.B2, bqv, c.L, D, r, c.alpha)
+                pk.Bq16, pk.Bv16 = bqv[:, 0], bqv[:, 1]                                 # [L, r, D] views (row stride D)
+            else:
+                if fl is not None:
+                    Aq, Av, Bq, Bv = fl.Aq, fl.Av, fl.Bq, fl.Bv
+                else:
+                    Aq = torch.stack([f32(b.attn.qkv.lora_q.A) for b in vit.blocks])
+                    Av = torch.stack([f32(b.attn.qkv.lora_v.A) for b in vit.blocks])
+                    Bq = torch.stack([f32(b.attn.qkv.lora_q.B) for b in vit.blocks])
+                    Bv = torch.stack([f32(b.attn.qkv.lora_v.B) for b in vit.blocks])
+                Acat = torch.cat([Aq, Av], dim=2).contiguous()                         # [L, D, 2r] f32
+                B2 = torch.zeros(c.L, 3 * D, 2 * r, device=dev, dtype=bf)
+                B2[:, :D, :r] = (c.alpha * Bq).transpose(1, 2)
+                B2[:, 2 * D:, r:] = (c.alpha * Bv).transpose(1, 2)
+                pk.B2 = B2
+                pk.AcatT = Acat.transpose(1, 2).to(bf).contiguous()
+                if not need_bwd:
+                    # inference: fold the adapters into the packed projection, W' = W + alpha * (A B)^T on the q and v rows
+                    # (SURVEY.md section 8f row 1 "LoRA merge"); the rank-2r K extension and the x @ A product disappear
+                    pk.wqkv_merged = []
+                    for l, blk in enumerate(vit.blocks):
+                        wm = f32(blk.attn.qkv.qkv.weight).clone()
+                        wm[:D] += c.alpha * (Aq[l] @ Bq[l]).t()
+                        wm[2 * D:] += c.alpha * (Av[l] @ Bv[l]).t()
+                        pk.wqkv_merged.append(wm.to(bf).contiguous())
+                else:
+                    pk.Acat16 = Acat.to(bf)
+                    pk.Bq16, pk.Bv16 = (c.alpha * Bq).to(bf).contiguous(), (c.alpha * Bv).to(bf).contiguous()
         if dec is None:   # encoder-only engine (bare registry model: embedding extraction)
             self._pack_key, self._pack = key, pk
             return pk
@@ -397,14 +406,22 @@ class HipEngine:
         w.mom = w.arena_f[offs[7]:offs[8]]
         w.mom_sum = w.arena_f[offs[8]:offs[9]]
         if train:
-            sizes_b = [NSLOTS * 2 * ch for ch in chans] + [0, 2]
-            w.arena_b = z(sum(sizes_b), dt=torch.float64)
+            # everything the backward pass accumulates into lives in ONE zero-filled byte buffer (one fill per step):
+            # f64 BN-backward statistics | f32 weight-gradient scratch of the TN GEMMs | head-bias slots
+            pixc = [8, 48, 96, _pad8(192 + D), _pad8(96 + 256), _pad8(48 + 128), _pad8(3 + 64)]
+            wsz = [9 * cp * ch for cp, ch in zip(pixc, chans)] + [c.NH * 9 * HEAD_C]
+            sizes_b = [NSLOTS * 2 * ch for ch in chans]
+            nb64, nw32, ns32 = sum(sizes_b), sum(wsz), 64 * 32
+            w.zbuf = z(nb64 * 8 + (nw32 + ns32) * 4, dt=torch.uint8)
+            w.arena_b = w.zbuf[:nb64 * 8].view(torch.float64)
+            w.wscr = w.zbuf[nb64 * 8:nb64 * 8 + nw32 * 4].view(torch.float32)
+            w.db3_slots = w.zbuf[nb64 * 8 + nw32 * 4:].view(torch.float32).view(64, 32)
             ob = [0]
             for s_ in sizes_b:
                 ob.append(ob[-1] + s_)
             w.stats_b = [w.arena_b[ob[i]:ob[i + 1]] for i in range(7)]
-            w.loss_acc = w.arena_b[ob[8]:ob[8] + 1]
-            w.sqn = w.arena_b[ob[8] + 1:ob[8] + 2]
+            w.scal = z(2, dt=torch.float64)          # loss accumulator | gradient square norm (one fill, in loss_and_grad)
+            w.loss_acc, w.sqn = w.scal[0:1], w.scal[1:2]
             # gradients / scratch
             w.dY = e(B, c.NH, S, S, dt=torch.float32)
             w.cscr = e(ops.heads_conv_bwd_scratch_bytes(B * S * S) // 4, dt=torch.float32)
@@ -412,21 +429,16 @@ class HipEngine:
             w.dXc = e(B * S * S, HEAD_C, dt=torch.float32)
             w.dF3 = e(B * S * S, HEAD_C)
             w.hscr = e(ops.heads_gate_bwd_scratch_bytes() // 4, dt=torch.float32)
-            w.db3_slots = z(64, 32, dt=torch.float32)
             w.dpre_c = [e(B * s1 * s1, 48), e(B * s2 * s2, 96), e(B * s3 * s3, 192)]
             w.dpre_f = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64), e(B * S * S, 32)]
             w.dcat = [e(B * s3 * s3, CONV_CH[3] + D), e(B * s2 * s2, CONV_CH[2] + FUS_OUT[0]),
                       e(B * s1 * s1, CONV_CH[1] + FUS_OUT[1]), e(B * S * S, FUS_OUT[2])]
             w.dFpost = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64)]
             w.dfeat = e(B, G, G, D)
-            pix = [B * s1 * s1, B * s2 * s2, B * s3 * s3, B * s3 * s3, B * s2 * s2, B * s1 * s1, B * S * S]
-            cinp = [8, 48, 96, _pad8(192 + D), _pad8(96 + 256), _pad8(48 + 128), _pad8(3 + 64)]
-            wsz = [9 * cp * ch for cp, ch in zip(cinp, chans)] + [c.NH * 9 * HEAD_C]
-            w.wscr = z(sum(wsz), dt=torch.float32)
             ow = [0]
             for s_ in wsz:
                 ow.append(ow[-1] + s_)
-            w.dWt = [w.wscr[ow[i]:ow[i + 1]].view(9 * cinp[i], chans[i]) for i in range(7)]
+            w.dWt = [w.wscr[ow[i]:ow[i + 1]].view(9 * pixc[i], chans[i]) for i in range(7)]
             w.dW3 = w.wscr[ow[7]:ow[8]].view(c.NH * 9, HEAD_C)
             self._alloc_encoder_bwd(w, c, e, z)
         self._ws[key] = w
@@ -462,13 +474,15 @@ class HipEngine:
             xin = w.x_in[l] if train else w.x_in[0]
             xmid = w.x_mid[i]
             xout = w.x_in[l + 1] if train else w.x_in[0]
-            ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
             if c.lora and not train:
+                ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
                 ops.gemm(w.h1[i], pk.wqkv_merged[l], w.qkv[i], bias=b.bqkv)
             elif c.lora:
-                ops.skinny_xw(w.h1[i], pk.AcatT[l], w.t[i])
+                # LN1 and the adapters' down-projection t = LN1(x) @ [A_q | A_v] in one pass over the row
+                ops.layernorm_lora_fwd(xin, b.n1w, b.n1b, w.h1[i], pk.AcatT[l], w.t[i], c.eps)
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv, a2=w.t[i], b2=pk.B2[l], K2=2 * c.rank)
             else:
+                ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
             ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale)
             ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32)
@@ -639,12 +653,10 @@ class HipEngine:
         S, s1, s2, s3, G = w.res
         dev = dY.device
         Mp = B * S * S
-        w.arena_b[:-2].zero_()
-        w.wscr.zero_()
+        w.zbuf.zero_()
         fl.gflat.zero_()
         dY = dY.to(torch.float32).contiguous()
         # ---- heads
-        w.db3_slots.zero_()
         ops.heads_conv_bwd(dY, w.out, w.F3, w.G, pk.W3k, w.cscr, w.dG, w.dXc, w.dW3, w.db3_slots, B, S, S, c.NH)
         fl.db3.add_(w.db3_slots.sum(0)[:c.NH])
         fl.dW3.add_(w.dW3.view(c.NH, 9, HEAD_C).transpose(1, 2))
@@ -706,13 +718,7 @@ class HipEngine:
                          conv=(r_out, r_out, cout, cout, r_in, r_in, 2), ldc=tgt.shape[-1], flags=ACCUM_BF16)
         # conv weight gradients: dWt [(ky,kx,c_pad), cout] -> parameter layout [cout, cin, ky, kx]
         for i, cv in enumerate(convs):
-            cp, cin = pk.cin_pad[i], pk.cin[i]
-            g = w.dWt[i].view(3, 3, cp, -1)[:, :, :cin].permute(3, 2, 0, 1)
-            gw = fl.gview[id(cv.conv.weight)]
-            if pk.perm[i] is not None:
-                gw.index_copy_(1, pk.perm[i], g)
-            else:
-                gw.copy_(g)
+            ops.unpack_conv3x3_wgrad(w.dWt[i], fl.gview[id(cv.conv.weight)], pk.cin_pad[i], rot=3 if pk.perm[i] is not None else 0)
         if on_decoder_done is not None:
             on_decoder_done()
         # ---- encoder (LoRA gradients; frozen weights need dgrad only)
@@ -771,7 +777,7 @@ class HipEngine:
     def loss_and_grad(self, out, target, marker_weights, lambda_factor):
         """WeightedMSELoss value (device scalar, f64) and dL/d(out) in the workspace."""
         w = self._saved.w
-        w.loss_acc.zero_()
+        w.scal.zero_()
         ops.wmse_fwd_bwd(out, target.to(torch.float32).contiguous(), marker_weights, w.loss_acc, w.dY, float(lambda_factor))
         B, C, H, W = out.shape
         return w.loss_acc * (float(lambda_factor) / (C * B * H * W)), w.dY
@@ -781,8 +787,7 @@ class HipEngine:
         if fl.m is None:
             fl.m, fl.v = torch.zeros_like(fl.flat), torch.zeros_like(fl.flat)
         fl.step += 1
-        w.sqn.zero_()
-        ops.sqnorm(fl.gflat, w.sqn)
+        ops.sqnorm(fl.gflat, w.sqn)       # (w.sqn was zeroed with the loss accumulator in loss_and_grad)
         ops.adam_clip_step(fl.flat, fl.gflat, fl.m, fl.v, w.sqn, float(lr), betas[0], betas[1], eps,
                            1.0 - betas[0] ** fl.step, 1.0 - betas[1] ** fl.step, float(max_norm),
                            nonfinite=self.nonfinite_flag())

@@ -136,6 +136,26 @@ def layernorm_fwd(x, w, b, out, eps=1e-6):
     return out
 
 
+def layernorm_lora_fwd(x, w, b, out, AcatT, t, eps=1e-6):
+    """out = bf16(LN(x)); t[M, 2r] = out @ AcatT^T (the LoRA down-projection of the block, fused into the LN1 pass)."""
+    M, D = x.shape
+    _chk_bf16(AcatT, "AcatT")
+    _chk_bf16(t, "t")
+    _call("mvit_layernorm_lora_fwd", _p(x), _p(w), _p(b), _p(out), _p(AcatT), _p(t), M, D, eps, AcatT.shape[0])
+    return out, t
+
+
+def lora_pack(lora_flat, AcatT, Acat, B2, Bqv, L, D, r, alpha):
+    assert lora_flat.dtype == torch.float32 and lora_flat.numel() == L * 4 * r * D
+    _call("mvit_lora_pack", _p(lora_flat), _p(AcatT), _p(Acat), _p(B2), _p(Bqv), L, D, r, float(alpha))
+
+
+def unpack_conv3x3_wgrad(dWt, dW, cin_pad, rot=0, accumulate=False):
+    cout, cin = dW.shape[0], dW.shape[1]
+    assert dWt.dtype == torch.float32 and dW.dtype == torch.float32 and dW.is_contiguous()
+    _call("mvit_unpack_conv3x3_wgrad", _p(dWt), _p(dW), cout, cin, cin_pad, rot, int(accumulate))
+
+
 def layernorm_bwd(dh, x, w, dx, gamma_next=None, dy=None, eps=1e-6, accumulate=True):
     M, D = x.shape
     _call("mvit_layernorm_bwd", _p(dh), _p(x), _p(w), _p(dx), _p(gamma_next), _p(dy), M, D, eps, int(accumulate))

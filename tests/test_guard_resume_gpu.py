@@ -69,6 +69,7 @@ def test_optimizer_state_survives_reflatten_and_checkpoint_resume():
     m3, v3, step3 = eng._flat.m.clone(), eng._flat.v.clone(), eng._flat.step
     assert step3 == 3 and float(m3.abs().sum()) > 0
     ckpt = mod.checkpoint_state()
+    p3 = _trainable(model)
     assert ckpt["global_step"] == 403 and ckpt["optimizer_state"]["step"] == 3
     assert all(k.startswith(("generator.", "loss_reconstruct.")) for k in ckpt["state_dict"])
     # (a) .cuda() / load_state_dict re-flatten the parameters: moments and step count carry over
@@ -86,8 +87,11 @@ def test_optimizer_state_survives_reflatten_and_checkpoint_resume():
     assert model2._engine._flat.step == 4
     got4 = _trainable(model2)
     for k in ref4:
-        d = float((got4[k] - ref4[k]).abs().max())
-        assert d <= 1e-6 + 1e-5 * float(ref4[k].abs().max()), (k, d)     # same kernels, same inputs (f32 atomics order aside)
+        d, moved = float((got4[k] - ref4[k]).abs().max()), float((ref4[k] - p3[k]).abs().max())
+        # same kernels, same inputs, same Adam state: the two 4th steps agree to a few % of the step itself (the gradients'
+        # f32 atomics are summed in a different order run to run, Adam's normalisation turns that into ~1e-5 moves); a lost or
+        # zeroed moment estimate would change the step by its own size
+        assert moved > 1e-3 and d < 0.1 * moved, (k, d, moved)
     # (c) a state of another architecture is rejected
     bad = dict(ckpt["optimizer_state"], layout=ckpt["optimizer_state"]["layout"][:-1])
     with pytest.raises(RuntimeError, match="optimizer state does not match"):

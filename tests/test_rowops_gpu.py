@@ -90,3 +90,56 @@ def test_patch_prefix_cast():
     o = torch.empty(50, 96, device="cuda", dtype=torch.bfloat16)
     ops.scale_cols_cast(xx, gam, o)
     assert torch.equal(o, (xx * gam).bfloat16())
+
+
+@pytest.mark.parametrize("M,D,r", [(7, 64, 4), (329 * 2, 96, 8), (5264, 1536, 8), (1301, 1536, 4)])
+def test_layernorm_lora_fused_matches_ln_then_matmul(M, D, r):
+    """LN1 + the LoRA down-projection in one pass: h identical to the plain LN kernel, t = bf16(h) @ bf16([A_q|A_v])."""
+    ops = _ops()
+    x = _rand(M, D, seed=1) * 3 + 0.5
+    w, b = _rand(D, seed=2) * 0.2 + 1, _rand(D, seed=3) * 0.1
+    AcatT = (_rand(2 * r, D, seed=7) * D ** -0.5).bfloat16()
+    h0 = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_fwd(x, w, b, h0, 1e-6)
+    h = torch.empty_like(h0)
+    t = torch.full((M, 2 * r), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_lora_fwd(x, w, b, h, AcatT, t, 1e-6)
+    assert torch.equal(h, h0)
+    ref = h0.float() @ AcatT.float().t()
+    assert bool(torch.isfinite(t.float()).all())
+    assert _rel(t.float(), ref) < 4e-3                       # bf16 output rounding
+    t2 = torch.empty_like(t)
+    ops.skinny_xw(h0, AcatT, t2)                             # the MFMA kernel it replaces
+    assert _rel(t.float(), t2.float()) < 4e-3
+
+
+def test_lora_pack_and_conv_wgrad_unpack():
+    ops = _ops()
+    L, D, r, alpha = 3, 96, 8, 0.5
+    flat = _rand(L * 4 * r * D, seed=11)
+    reg = flat.view(L, 4, r * D)
+    Aq, Bq, Av, Bv = reg[:, 0].view(L, D, r), reg[:, 1].view(L, r, D), reg[:, 2].view(L, D, r), reg[:, 3].view(L, r, D)
+    bf = torch.bfloat16
+    AcatT = torch.empty(L, 2 * r, D, device="cuda", dtype=bf)
+    Acat = torch.empty(L, D, 2 * r, device="cuda", dtype=bf)
+    B2 = torch.full((L, 3 * D, 2 * r), 7.0, device="cuda", dtype=bf)
+    Bqv = torch.empty(L, 2, r, D, device="cuda", dtype=bf)
+    ops.lora_pack(flat, AcatT, Acat, B2, Bqv, L, D, r, alpha)
+    cat = torch.cat([Aq, Av], dim=2)
+    assert torch.equal(Acat, cat.to(bf)) and torch.equal(AcatT, cat.transpose(1, 2).to(bf))
+    ref = torch.zeros(L, 3 * D, 2 * r, device="cuda")
+    ref[:, :D, :r] = (alpha * Bq).transpose(1, 2)
+    ref[:, 2 * D:, r:] = (alpha * Bv).transpose(1, 2)
+    assert torch.equal(B2, ref.to(bf))
+    assert torch.equal(Bqv[:, 0], (alpha * Bq).to(bf)) and torch.equal(Bqv[:, 1], (alpha * Bv).to(bf))
+    for cout, cin, cp, rot in [(32, 67, 72, 3), (48, 3, 8, 0), (256, 1728, 1728, 0)]:
+        dWt = _rand(9 * cp, cout, seed=cout)
+        dW = torch.empty(cout, cin, 3, 3, device="cuda")
+        ops.unpack_conv3x3_wgrad(dWt, dW, cp, rot=rot)
+        g = dWt.view(3, 3, cp, cout)[:, :, :cin].permute(3, 2, 0, 1)
+        want = torch.empty_like(dW)
+        perm = (torch.arange(cin, device="cuda") + rot) % cin
+        want[:, perm] = g
+        assert torch.equal(dW, want)
+        ops.unpack_conv3x3_wgrad(dWt, dW, cp, rot=rot, accumulate=True)
+        assert torch.allclose(dW, 2 * want)
