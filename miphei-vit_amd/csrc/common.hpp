@@ -69,6 +69,19 @@ static inline int mvit_ensure_dynamic_lds(const void* fn, size_t bytes, mvit_per
   return MVIT_OK;
 }
 
+// CU count of the current device (cached per device)
+static inline int mvit_num_cus() {
+  static std::atomic<int> cus[MVIT_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return 256;
+  int cu = cus[dev].load(std::memory_order_relaxed);
+  if (cu <= 0) {
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    cus[dev].store(cu, std::memory_order_relaxed);
+  }
+  return cu;
+}
+
 static inline int hip_ok(hipError_t e) { return e == hipSuccess ? MVIT_OK : (int)e; }
 #define MVIT_LAUNCH_CHECK() hip_ok(hipGetLastError())
 // hipGetLastError() reports (and resets) the last error of ANY earlier HIP call of this thread, including benign

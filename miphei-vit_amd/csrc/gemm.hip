@@ -5,17 +5,7 @@
 static int dispatch(const mvit_gemm_args& a, hipStream_t s);
 
 namespace mvit_gemm {
-int gemm_num_cus() {
-  static std::atomic<int> cus[MVIT_MAX_DEVICES];  // per device (zero = not asked yet)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return 256;
-  int cu = cus[dev].load(std::memory_order_relaxed);
-  if (cu <= 0) {
-    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
-    cus[dev].store(cu, std::memory_order_relaxed);
-  }
-  return cu;
-}
+int gemm_num_cus() { return mvit_num_cus(); }
 }  // namespace mvit_gemm
 
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {

@@ -59,32 +59,55 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // v_dot2c_f32_bf16 (same products as the bf16 MFMA path: bf16 x bf16, f32 accumulate) and the R2 partial sums are
 // reduced across the wave with a halving butterfly (R2/2 + R2/4 + ... exchanges instead of 6 per value).
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_v;
-__global__ __launch_bounds__(256) void ln_fwd_lora_kernel(const float* __restrict__ x, const float* __restrict__ w,
+constexpr int LNL_WAVES = 8;   // waves per block sharing one LDS image of the adapters; two blocks per CU (<= 128 VGPRs)
+template <int NV>  // float4 groups per lane: D <= 256 * NV
+__global__ __launch_bounds__(64 * LNL_WAVES, 4) void ln_fwd_lora_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ b, bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t, int M, int D,
                                                           float eps, int R2) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   uint2* As = (uint2*)lds_raw;                       // [R2][D/4] groups of 4 bf16
   const int nv = D >> 2;
-  for (int i = threadIdx.x; i < R2 * nv; i += 256) As[i] = ((const uint2*)AcatT)[i];
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float4* xr = (const float4*)(x + (size_t)row * D);
-    float4 v[LN_MAXV];
+  const int row0 = blockIdx.x * LNL_WAVES + wave;
+  // Persistent blocks, a wave walks rows row0, row0 + (waves in the grid), ...: the adapter image (L2-resident, 16-byte pieces) is
+  // staged once per block, and the NEXT row's loads are issued before the current row is reduced, so a second trip costs its
+  // arithmetic, not another HBM round trip.
+  const int stride = gridDim.x * LNL_WAVES;
+  float4 vn[NV];
+  auto load_row = [&](int r) __attribute__((always_inline)) {
+    const float4* xr = (const float4*)(x + (size_t)(r < M ? r : M - 1) * D) + lane;   // + 64 * i: immediate offsets
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < nv) vn[i] = xr[64 * i];
+    }
+  };
+  load_row(row0);
+  {
+    // LDS image [R2][NV * 64] groups (row stride fixed at compile time: every ds_read of the dot phase is base + immediate)
+    const int h = nv >> 1;                           // 16-byte pieces per adapter row (D % 8 == 0 is checked by the host)
+    for (int i = threadIdx.x; i < R2 * h; i += 64 * LNL_WAVES) {
+      const int j = i / h, c = i - j * h;
+      ((uint4*)lds_raw)[j * (NV * 32) + c] = ((const uint4*)AcatT)[i];
+    }
+  }
+  __syncthreads();
+  for (int row = row0; row < M; row += stride) {
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = vn[i];
+    if (row + stride < M) load_row(row + stride);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int idx = lane + 64 * i;
-      if (idx < nv) {
-        v[i] = xr[idx];
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      }
+      if (idx < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mu = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int idx = lane + 64 * i;
       if (idx < nv) {
         const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
@@ -92,25 +115,37 @@ __global__ __launch_bounds__(256) void ln_fwd_lora_kernel(const float* __restric
       }
     }
     const float rs = rsqrtf(wave_sum(q) / D + eps);
-    uint2* o = (uint2*)(out + (size_t)row * D);
+    uint2* o = (uint2*)(out + (size_t)row * D) + lane;
+    const float4* wl = (const float4*)w + lane;
+    const float4* bl = (const float4*)b + lane;
+    uint2 rp[NV];                                    // the normalised row as packed bf16 (what the qkv GEMM will read)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < nv) {
+        const float4 ww = wl[64 * i], bv = bl[64 * i];
+        rp[i].x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
+        rp[i].y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
+        o[64 * i] = rp[i];
+      }
+      // (the scale / shift vectors of at most two groups in flight: hoisting all NV pairs costs 8 registers each)
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);               // the f32 row is dead from here on: keep the dot phase out of its live range
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int idx = lane + 64 * i;
+      __builtin_amdgcn_sched_barrier(0);
       if (idx < nv) {
-        const float4 ww = ((const float4*)w)[idx], bv = ((const float4*)b)[idx];
-        uint2 r;
-        r.x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
-        r.y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
-        o[idx] = r;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           if (j < R2) {
-            const uint2 a = As[j * nv + idx];
-            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&r.x, *(const bf16x2_v*)&a.x, acc[j], false);
-            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&r.y, *(const bf16x2_v*)&a.y, acc[j], false);
+            const uint2 a = As[j * (NV * 64) + idx];
+            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&rp[i].x, *(const bf16x2_v*)&a.x, acc[j], false);
+            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&rp[i].y, *(const bf16x2_v*)&a.y, acc[j], false);
           }
         }
       }
@@ -358,15 +393,20 @@ MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, 
 MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float* b, void* out, const void* AcatT, void* t,
                                      int M, int D, float eps, int R2, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV || R2 <= 0 || R2 > 16 || !AcatT || !t) return MVIT_EINVAL;
-  const size_t lds = (size_t)R2 * D * 2;
-  static mvit_per_device_size raised;
-  if (mvit_ensure_dynamic_lds((const void*)ln_fwd_lora_kernel, lds, raised) != MVIT_OK) return MVIT_EINVAL;
-  // persistent blocks (the 48 KB adapter image is loaded once per block): three per CU fit the LDS
-  const int blocks = (M + 3) / 4 < 768 ? (M + 3) / 4 : 768;
-  hipLaunchKernelGGL(ln_fwd_lora_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, w, b, (bf16_t*)out,
-                     (const bf16_t*)AcatT, (bf16_t*)t, M, D, eps, R2);
-  return MVIT_LAUNCH_CHECK();
+  if (M <= 0 || D <= 0 || (D & 7) || D > 256 * LN_MAXV || R2 <= 0 || R2 > 16 || !AcatT || !t) return MVIT_EINVAL;
+  const size_t lds = (size_t)R2 * ((D + 511) / 512 * 512) * 2;   // rows padded to the kernel's compile-time stride
+  auto launch = [&](auto kern, mvit_per_device_size& raised) {
+    if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return (int)MVIT_EINVAL;
+    const int want = (M + LNL_WAVES - 1) / LNL_WAVES, cap = 2 * mvit_num_cus();   // two resident blocks per CU
+    hipLaunchKernelGGL(kern, dim3(want < cap ? want : cap), dim3(64 * LNL_WAVES), lds, (hipStream_t)stream, x, w, b,
+                       (bf16_t*)out, (const bf16_t*)AcatT, (bf16_t*)t, M, D, eps, R2);
+    return MVIT_LAUNCH_CHECK();
+  };
+  static mvit_per_device_size r2, r4, r6, r8;
+  if (D <= 512) return launch(ln_fwd_lora_kernel<2>, r2);
+  if (D <= 1024) return launch(ln_fwd_lora_kernel<4>, r4);
+  if (D <= 1536) return launch(ln_fwd_lora_kernel<6>, r6);
+  return launch(ln_fwd_lora_kernel<8>, r8);
 }
 
 MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, float* dx, const float* gamma_next,

@@ -207,3 +207,50 @@ def test_gemm_tn_conv_wgrad(B, H, W, C, Cout, stride):
         dy.float().view(B, OH, OW, Cout).permute(0, 3, 1, 2))
     ref = w.grad.permute(2, 3, 1, 0).reshape(9 * C, Cout)
     assert _rel(dwt, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(5264, 4608, 1536), (5264, 4608, 448), (5264, 4608, 384), (5000, 4096, 1600), (21056, 1536, 512)])
+def test_gemm_store_persistent_blocks(M, N, K):
+    """More tiles than blocks (persistent blocks walk several tiles, the next tile's first K tiles are in flight while the
+    epilogue of the current one runs); short K loops, ragged last row tile; repeated launches must agree bit for bit."""
+    ops = _ops()
+    b = _rand(N, K, seed=2).bfloat16()
+    bias = _rand(N, seed=3)
+    outs = []
+    for rep in range(3):
+        a = _rand(M, K, seed=10 + rep).bfloat16()
+        c = torch.full((M + 8, N), 7.0, device="cuda", dtype=torch.bfloat16)      # guard rows behind the matrix
+        ops.gemm(a, b, c[:M], bias=bias)
+        ref = a.float() @ b.float().t() + bias
+        assert _rel(c[:M].float(), ref) < 4e-3
+        assert float((c[:M].float() - ref).abs().max()) < 0.05 * float(ref.abs().max())   # no stale / misplaced 16-byte piece
+        assert bool((c[M:] == 7.0).all())
+        c2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, b, c2, bias=bias)
+        assert torch.equal(c[:M], c2)
+        outs.append(c2)
+    assert not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,D,H,with_aux", [(5264, 1536, 4096, True), (5264, 448, 2048, True), (5264, 1536, 4096, False)])
+def test_gemm_swiglu_persistent_blocks(M, D, H, with_aux):
+    ops = _ops()
+    idx = _pack_swiglu_rows(H).cuda()
+    w = _rand(2 * H, D, seed=2, scale=D ** -0.5)
+    bias = _rand(2 * H, seed=3, scale=0.1)
+    wp, bp = w[idx].bfloat16().contiguous(), bias[idx].contiguous()
+    for rep in range(2):
+        x = _rand(M, D, seed=20 + rep).bfloat16()
+        g = torch.full((M + 4, H), 7.0, device="cuda", dtype=torch.bfloat16)
+        u = torch.full((M + 4, 2 * H), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(x, wp, g[:M], bias=bp, aux=(u[:M] if with_aux else None), epi=ops.EPI_SWIGLU)
+        uref = x.float() @ w.bfloat16().float().t() + bias
+        a, b = uref[:, :H], uref[:, H:]
+        ref = F.silu(a) * b
+        assert _rel(g[:M].float(), ref) < 5e-3
+        assert float((g[:M].float() - ref).abs().max()) < 0.05 * float(ref.abs().max()) + 0.05
+        assert bool((g[M:] == 7.0).all())
+        if with_aux:
+            assert _rel(u[:M].float()[:, idx.argsort()], uref) < 4e-3 and bool((u[M:] == 7.0).all())
+        else:
+            assert bool((u == 7.0).all())
