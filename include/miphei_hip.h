@@ -252,12 +252,19 @@ MVIT_API int mvit_u8_nhwc_to_f32_nchw(const void* src_u8, float* dst, const floa
 MVIT_API int mvit_f32_to_u8_export(const float* src, void* dst_u8, long long n, mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- validation-time cell extractor */
-/* For every pixel with 0 < nuclei[b,p] <= max_label: counts[b,lab] += 1, sums_pred[b,lab,c] += pred[b,c,p] (and the same
- * for target when given).  Tables are [B, max_label+1, C] / [B, max_label+1] f32, zeroed by the caller.
- * MeanCellExtrator.extract_mean, src/utils.py:49-121 (torch.unique + scatter_add_ per image). */
-MVIT_API int mvit_cell_sums(const float* pred, const float* target, const int* nuclei, float* sums_pred,
-                            float* sums_target, float* counts, int B, int C, long long HW, int max_label,
-                            mvit_stream_t stream);
+/* Per-nucleus statistics of a batch as a segmented reduction over the label map (ids are slide-global: nothing is sized by the
+ * label value).  Replaces MeanCellExtrator.forward / extract_mean (src/utils.py:23-121: F.interpolate 'area' of pred / target and
+ * 'nearest-exact' of the label map when scale_factor < 1, then per image torch.unique + scatter_add_ + divide) and the reduction of
+ * CellMetrics.update (src/metrics.py:38-74; want_sums != 0 returns sums instead of means).
+ *   pred / target: f32 [B,C,H,W] (target may be NULL), nuclei: int32 or int64 [B,H,W], C <= 32, 0 < scale_factor <= 1.
+ *   scratch: rec_count [B] int, rec_key [B,rmax] int, rec_val [B,rmax,2C+1] f32 (rmax a power of two <= 8192: partial records
+ *   per image, one per (tile, nucleus) pair).
+ *   outputs, per image b: n_unique[b]; rows [b, 0 .. n_unique[b]) of out_ids (ascending), out_count, out_pred [.,C], out_target.
+ * A host that finds rec_count[b] > rmax must treat the result as invalid (more nucleus fragments than the scratch holds). */
+MVIT_API int mvit_cell_means(const float* pred, const float* target, const void* nuclei, int label_is_int64, int B, int C, int H,
+                             int W, float scale_factor, int rmax, int want_sums, int* rec_count, int* rec_key, float* rec_val,
+                             int* n_unique, int* out_ids, float* out_count, float* out_pred, float* out_target,
+                             mvit_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -80,7 +80,7 @@ SIGNATURES = {
     "mvit_sqnorm": [vp, vp, ll, vp],
     "mvit_u8_nhwc_to_f32_nchw": [vp, vp, vp, vp, ci, ci, ll, vp],
     "mvit_f32_to_u8_export": [vp, vp, ll, vp],
-    "mvit_cell_sums": [vp, vp, vp, vp, vp, vp, ci, ci, ll, ci, vp],
+    "mvit_cell_means": [vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mvit_adam_clip_step": [vp, vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, cf, vp, vp],
 }
 

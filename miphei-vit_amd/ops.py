@@ -331,7 +331,21 @@ def f32_to_u8_export(src, dst):
     return dst
 
 
-def cell_sums(pred, target, nuclei, sums_p, sums_t, counts, max_label):
+def cell_means(pred, target, nuclei, scale_factor=1.0, want_sums=False, rmax=8192):
+    """Per-image (n_unique [B] int32, ids [B,rmax] int32, counts [B,rmax] f32, pred stats [B,rmax,C], target stats or None) of the
+    segmented reduction over the nucleus label map (mvit_cell_means); valid rows of image b: [0, n_unique[b])."""
     B, Cc, H, W = pred.shape
-    assert nuclei.dtype == torch.int32
-    _call("mvit_cell_sums", _p(pred), _p(target), _p(nuclei), _p(sums_p), _p(sums_t), _p(counts), B, Cc, H * W, max_label)
+    assert pred.dtype == torch.float32 and pred.is_contiguous() and nuclei.is_contiguous() and tuple(nuclei.shape) == (B, H, W)
+    assert nuclei.dtype in (torch.int32, torch.int64)
+    dev = pred.device
+    rec_count = torch.empty(B, device=dev, dtype=torch.int32)
+    rec_key = torch.empty(B, rmax, device=dev, dtype=torch.int32)
+    rec_val = torch.empty(B, rmax, 2 * Cc + 1, device=dev, dtype=torch.float32)
+    n_unique = torch.empty(B, device=dev, dtype=torch.int32)
+    ids = torch.empty(B, rmax, device=dev, dtype=torch.int32)
+    cnt = torch.empty(B, rmax, device=dev, dtype=torch.float32)
+    op = torch.empty(B, rmax, Cc, device=dev, dtype=torch.float32)
+    ot = torch.empty(B, rmax, Cc, device=dev, dtype=torch.float32) if target is not None else None
+    _call("mvit_cell_means", _p(pred), _p(target), _p(nuclei), int(nuclei.dtype == torch.int64), B, Cc, H, W, float(scale_factor),
+          rmax, int(want_sums), _p(rec_count), _p(rec_key), _p(rec_val), _p(n_unique), _p(ids), _p(cnt), _p(op), _p(ot))
+    return rec_count, n_unique, ids, cnt, op, ot

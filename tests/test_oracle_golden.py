@@ -157,3 +157,32 @@ def test_vit_matches_hf_dinov2_with_registers(swiglu):
         ref = m(pixel_values=x).last_hidden_state
         mine = vit_forward(p, x, cfg, prefix="", lora=False)
     assert _rel(mine.numpy(), ref.numpy()) < 1e-5
+
+
+def test_oracle_cells_match_reference_fixture(golden_dir):
+    """MeanCellExtrator (scale 1 / 0.5 / 0.25, target=None) and CellMetrics.update state, captured from the reference's classes."""
+    from oracle.cells import cell_metrics_update, extract_means
+    from oracle.detgen import det_normal
+    g = np.load(os.path.join(golden_dir, "comp_cells.npz"))
+    seed, B, C, H, W = (int(g[k]) for k in ("seed", "B", "C", "H", "W"))
+    T = lambda name, shape, std=1.0: np.asarray(det_normal(seed, name, shape, 0.0, std), dtype=np.float32)
+    pred, target = np.tanh(T("pred", (B, C, H, W))), np.clip(T("target", (B, C, H, W), 0.5), -0.9, 0.9)
+    pred = torch.tanh(torch.from_numpy(T("pred", (B, C, H, W)))).numpy()    # the same tanh the fixture script applied
+    nuclei = g["nuclei"]
+    for tag, sf in (("s1", 1.0), ("s05", 0.5), ("s025", 0.25)):
+        pm, tm, ids, _ = extract_means(pred, target, nuclei, sf)
+        assert np.array_equal(ids, g[f"ids_{tag}"])                          # labels and their order: exact
+        assert np.allclose(pm, g[f"pm_{tag}"], atol=2e-6) and np.allclose(tm, g[f"tm_{tag}"], atol=2e-6)
+    pm, tm, _, _ = extract_means(pred, None, nuclei[:, None], 1.0)
+    assert np.allclose(pm, g["pm_notarget"], atol=2e-6) and not tm.any() and not g["tm_notarget"].any()
+    st = cell_metrics_update(pred, nuclei, [1, 2, 3, 4])
+    slides = ["slideA", "slideB", "slideA", "slideB"]
+    seen = {"slideA": 0, "slideB": 0}
+    for b, rec in enumerate(st):
+        if rec is None:
+            continue
+        s, i = slides[b], seen[slides[b]]
+        seen[s] += 1
+        assert np.array_equal(rec[0], g[f"cm_{s}_id{i}"]) and np.array_equal(rec[2], g[f"cm_{s}_area{i}"])
+        assert np.abs(rec[1] - g[f"cm_{s}_sum{i}"]).max() <= 1               # truncation of sums*255 to uint32: f32 summation order
+    assert seen == {"slideA": int(g["cm_slideA_n"]), "slideB": int(g["cm_slideB_n"])}
