@@ -91,6 +91,9 @@ def test_optimizer_state_survives_reflatten_and_checkpoint_resume():
         # same kernels, same inputs, same Adam state: the two 4th steps agree to a few % of the step itself (the gradients'
         # f32 atomics are summed in a different order run to run, Adam's normalisation turns that into ~1e-5 moves); a lost or
         # zeroed moment estimate would change the step by its own size
+        if moved == 0.0:          # bias in front of a train-mode BatchNorm: its gradient is exactly zero
+            assert d == 0.0, k
+            continue
         assert moved > 1e-3 and d < 0.1 * moved, (k, d, moved)
     # (c) a state of another architecture is rejected
     bad = dict(ckpt["optimizer_state"], layout=ckpt["optimizer_state"]["layout"][:-1])
