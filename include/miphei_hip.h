@@ -56,6 +56,8 @@ typedef struct mvit_gemm_args {
   const void* A2; const void* B2;
   const float* bias; const float* gamma;
   void* aux; const float* pos; double* stats;
+  const float* rowscale;   /* EPI_RESID: optional per-row factor of the branch, C = aux + rowscale[row]*gamma*(acc+bias): timm DropPath
+                              (stochastic depth, per sample) around the LayerScale'd branch; NULL = 1 */
   int M, N, K, K2;
   int lda, ldb, ldc, lda2, ldb2, ldaux;
   int epi, flags, ksplit, amode;
@@ -103,9 +105,11 @@ MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, 
 MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float* b, void* out, const void* AcatT, void* t,
                                      int M, int D, float eps, int R2, mvit_stream_t stream);
 /* dx (+)= dLN/dx(dh); statistics recomputed from x.  If gamma_next/dy are given also writes
- * dy(bf16) = gamma_next * dx_total (the LayerScale-scaled gradient of the preceding residual branch). */
+ * dy(bf16) = rowscale_next[row] * gamma_next * dx_total (the LayerScale-scaled gradient of the preceding residual branch;
+ * rowscale_next = that branch's per-sample DropPath factors, NULL = 1). */
 MVIT_API int mvit_layernorm_bwd(const void* dh_bf16, const float* x, const float* w, float* dx, const float* gamma_next,
-                                void* dy_bf16, int M, int D, float eps, int accumulate, mvit_stream_t stream);
+                                void* dy_bf16, int M, int D, float eps, int accumulate, const float* rowscale_next,
+                                mvit_stream_t stream);
 /* out(bf16)[M,R] = X(bf16)[M,K] @ W(bf16)[R,K]^T, R <= 16 (one wave per 16 rows on the 16x16x32 MFMA).
  * LoRALayer.forward x @ A (src/generators/lora.py:16-18) and its adjoint dq @ B^T. */
 MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void* out, int ldo, int M, int K, int R,
@@ -119,8 +123,9 @@ MVIT_API int mvit_im2col_patch(const float* img, void* out_bf16, int B, int S, i
 MVIT_API int mvit_prefix_tokens(float* x, const float* cls, const float* reg, int B, int ntok, int D, int R,
                                 mvit_stream_t stream);
 MVIT_API int mvit_cast_f32_bf16(const float* src, void* dst_bf16, long long n, mvit_stream_t stream);
-/* out(bf16)[M,D] = x(f32)[M,D] * gamma[D] */
-MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out_bf16, int M, int D, mvit_stream_t stream);
+/* out(bf16)[M,D] = x(f32)[M,D] * gamma[D] * rowscale[M] (rowscale may be NULL) */
+MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out_bf16, int M, int D, const float* rowscale,
+                                  mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- fused multi-head attention */
 /* out(bf16)[B,N,H*Dh] = softmax(q k^T * scale) v per head, reading the packed projection qkv(bf16)[B,N,3,H,Dh];
@@ -152,16 +157,20 @@ MVIT_API int mvit_image_to_nhwc(const float* img, void* dst, int B, int S, int C
 MVIT_API int mvit_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
                               int nslots, double count, float eps, float momentum, int training, mvit_stream_t stream);
+/* out = dropout(relu(x*scale + shift)).  drop_p in [0,1): nn.Dropout(p) of Conv2DBlock / Deconv2DBlock in train mode
+ * (src/generators/unet.py:441-519; 0 = off, the MIPHEI-ViT decoder has none): element e of the [M, C] activation is kept iff the
+ * 16-bit field (e & 3) of splitmix64(drop_seed + (e >> 2) * 0x9E3779B97F4A7C15) is >= round(drop_p * 65536), kept values are
+ * scaled by 1 / (1 - round(drop_p*65536)/65536).  The backward entry points recompute the same mask from (drop_seed, e). */
 MVIT_API int mvit_bn_relu_apply(const void* x, const float* scale, const float* shift, void* out, long long M, int C,
-                                int ld_x, int ld_out, mvit_stream_t stream);
-/* backward of relu(BN(x)): reduce (sum g, sum g*xhat into [nslots][2][C] f64) then apply (dx, dgamma+=, dbeta+=). */
+                                int ld_x, int ld_out, float drop_p, unsigned long long drop_seed, mvit_stream_t stream);
+/* backward of dropout(relu(BN(x))): reduce (sum g, sum g*xhat into [nslots][2][C] f64) then apply (dx, dgamma+=, dbeta+=). */
 MVIT_API int mvit_bn_relu_bwd_reduce(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
                                      const float* mean, const float* rstd, double* stats, long long M, int C, int nslots,
-                                     mvit_stream_t stream);
+                                     float drop_p, unsigned long long drop_seed, mvit_stream_t stream);
 MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
                                     const float* mean, const float* rstd, const float* gamma, const double* stats,
                                     float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
-                                    mvit_stream_t stream);
+                                    float drop_p, unsigned long long drop_seed, mvit_stream_t stream);
 /* dst[c][r] = src[r][c] (bf16). */
 /* nn.Conv2d weight [Cout,Cin,3,3] f32 -> the packed bf16 operands of the implicit-GEMM convolution (mipheivit.py:20-31):
  * wk [Cout, 9*Cp] (forward), wd [Cp, 9*Cout] (dgrad, may be NULL); packed channel c = source channel (c+rot) mod Cin */

@@ -21,7 +21,7 @@ vp, ci, cf, cd, ll = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong
 class GemmArgs(C.Structure):
     _fields_ = [
         ("A", vp), ("B", vp), ("C", vp), ("A2", vp), ("B2", vp), ("bias", vp), ("gamma", vp),
-        ("aux", vp), ("pos", vp), ("stats", vp),
+        ("aux", vp), ("pos", vp), ("stats", vp), ("rowscale", vp),
         ("M", ci), ("N", ci), ("K", ci), ("K2", ci),
         ("lda", ci), ("ldb", ci), ("ldc", ci), ("lda2", ci), ("ldb2", ci), ("ldaux", ci),
         ("epi", ci), ("flags", ci), ("ksplit", ci), ("amode", ci),
@@ -48,21 +48,21 @@ SIGNATURES = {
     "mvit_layernorm_lora_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
     "mvit_lora_pack": [vp, vp, vp, vp, vp, ci, ci, ci, cf, vp],
     "mvit_unpack_conv3x3_wgrad": [vp, vp, ci, ci, ci, ci, ci, vp],
-    "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
+    "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp],
     "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
     "mvit_skinny_xw2": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "mvit_im2col_patch": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_prefix_tokens": [vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_cast_f32_bf16": [vp, vp, C.c_longlong, vp],
-    "mvit_scale_cols_cast": [vp, vp, vp, ci, ci, vp],
+    "mvit_scale_cols_cast": [vp, vp, vp, ci, ci, vp, vp],
     "mvit_attention_fwd": [vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_attention_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_resample2d": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ll, ll, ci, vp],
     "mvit_image_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_bn_finalize": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cf, cf, ci, vp],
-    "mvit_bn_relu_apply": [vp, vp, vp, vp, ll, ci, ci, ci, vp],
-    "mvit_bn_relu_bwd_reduce": [vp, ci, vp, vp, vp, vp, vp, vp, ll, ci, ci, vp],
-    "mvit_bn_relu_bwd_apply": [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, cd, vp],
+    "mvit_bn_relu_apply": [vp, vp, vp, vp, ll, ci, ci, ci, cf, C.c_ulonglong, vp],
+    "mvit_bn_relu_bwd_reduce": [vp, ci, vp, vp, vp, vp, vp, vp, ll, ci, ci, cf, C.c_ulonglong, vp],
+    "mvit_bn_relu_bwd_apply": [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, cd, cf, C.c_ulonglong, vp],
     "mvit_pack_conv3x3_weights": [vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_pixel_shuffle2x": [vp, vp, ci, ci, ci, ci, ll, ci, vp],
     "mvit_transpose_bf16": [vp, vp, ci, ci, ci, ll, vp],

@@ -131,9 +131,33 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, const float
   if (rstd_o) rstd_o[c] = (float)rstd;
 }
 
+// Counter-based dropout mask (nn.Dropout after the ReLU of Conv2DBlock / Deconv2DBlock, src/generators/unet.py:441-519): element
+// e of a [M, C] activation is kept iff the 16-bit field (e & 3) of splitmix64(seed + (e >> 2) * golden) is >= p * 65536; kept
+// values are scaled by 1 / (1 - p).  Forward and backward recompute the same mask from (seed, element index): nothing is stored.
+struct DropCfg {
+  unsigned long long seed;
+  unsigned thresh;   // p * 65536 (0: dropout off)
+  float inv_keep;
+};
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// multipliers of 8 consecutive elements starting at element index e0 (e0 % 8 == 0)
+__device__ __forceinline__ void drop8(const DropCfg& d, unsigned long long e0, float (&f)[8]) {
+  if (d.thresh == 0) return;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const unsigned long long z = splitmix64(d.seed + ((e0 >> 2) + h) * 0x9E3779B97F4A7C15ull);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[4 * h + j] *= ((unsigned)(z >> (16 * j)) & 0xffffu) >= d.thresh ? d.inv_keep : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, bf16_t* __restrict__ out,
-                                                            long long M, int C, int ld_x, int ld_out) {
+                                                            long long M, int C, int ld_x, int ld_out, DropCfg drop) {
   const int cv = C >> 3;
   const long long total = M * cv;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -143,6 +167,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const bf16_t* __rest
     unpack8(*(const uint4*)(x + (size_t)m * ld_x + c8 * 8), f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * scale[c8 * 8 + j] + shift[c8 * 8 + j], 0.f);
+    drop8(drop, (unsigned long long)m * C + c8 * 8, f);
     *(uint4*)(out + (size_t)m * ld_out + c8 * 8) = pack8f(f);
   }
 }
@@ -153,7 +178,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                 double* __restrict__ stats, long long M, int C, int nslots) {
+                                                                 double* __restrict__ stats, long long M, int C, int nslots,
+                                                                 DropCfg drop) {
   __shared__ float red[2 * 512];
   for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
   __syncthreads();
@@ -170,6 +196,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* _
       float g[8], xv[8];
       unpack8(*(const uint4*)(dy + (size_t)m * ld_dy + c8 * 8), g);
       unpack8(*(const uint4*)(x + (size_t)m * C + c8 * 8), xv);
+      drop8(drop, (unsigned long long)m * C + c8 * 8, g);   // gradient through the dropout that followed the ReLU
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float gg = (xv[j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const double* __restrict__ stats, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, bf16_t* __restrict__ dx,
-                                                                long long M, int C, int nslots, double count) {
+                                                                long long M, int C, int nslots, double count, DropCfg drop) {
   __shared__ float s1s[512], s2s[512];
   for (int c = threadIdx.x; c < C; c += 256) {
     double a = 0., b = 0.;
@@ -219,6 +246,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __
     float g[8], xv[8];
     unpack8(*(const uint4*)(dy + (size_t)m * ld_dy + c8 * 8), g);
     unpack8(*(const uint4*)(x + (size_t)m * C + c8 * 8), xv);
+    drop8(drop, (unsigned long long)m * C + c8 * 8, g);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c8 * 8 + j;
@@ -244,6 +272,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     const int c = i >> 6, r = i & 63;
     if (r0 + r < R && c0 + c < Cc) dst[(size_t)(c0 + c) * ld_dst + r0 + r] = tile[r][c];
   }
+}
+
+inline DropCfg make_drop(float p, unsigned long long seed) {
+  DropCfg d;
+  d.seed = seed;
+  d.thresh = p > 0.f ? (unsigned)(p * 65536.f + 0.5f) : 0u;
+  d.inv_keep = p > 0.f ? 1.f / (1.f - (float)d.thresh / 65536.f) : 1.f;
+  return d;
 }
 
 inline int nblk(long long work, int per, int cap = 16384) {
@@ -348,34 +384,35 @@ MVIT_API int mvit_bn_finalize(const double* stats, const float* gamma, const flo
 }
 
 MVIT_API int mvit_bn_relu_apply(const void* x, const float* scale, const float* shift, void* out, long long M, int C,
-                                int ld_x, int ld_out, mvit_stream_t stream) {
+                                int ld_x, int ld_out, float drop_p, unsigned long long drop_seed, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || C <= 0 || (C & 7) || (ld_x & 7) || (ld_out & 7)) return MVIT_EINVAL;
+  if (M <= 0 || C <= 0 || (C & 7) || (ld_x & 7) || (ld_out & 7) || !(drop_p >= 0.f && drop_p < 1.f)) return MVIT_EINVAL;
   hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(nblk(M * (C >> 3), 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, scale, shift, (bf16_t*)out, M, C, ld_x, ld_out);
+                     (const bf16_t*)x, scale, shift, (bf16_t*)out, M, C, ld_x, ld_out, make_drop(drop_p, drop_seed));
   return MVIT_LAUNCH_CHECK();
 }
 
 MVIT_API int mvit_bn_relu_bwd_reduce(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
                                      const float* mean, const float* rstd, double* stats, long long M, int C, int nslots,
-                                     mvit_stream_t stream) {
+                                     float drop_p, unsigned long long drop_seed, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
+  if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return MVIT_EINVAL;
   const int rpb = 256 / (C >> 3);
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk(M, rpb * 16, 2048)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, stats, M, C, nslots);
+                     (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, stats, M, C, nslots,
+                     make_drop(drop_p, drop_seed));
   return MVIT_LAUNCH_CHECK();
 }
 
 MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, const float* scale, const float* shift,
                                     const float* mean, const float* rstd, const float* gamma, const double* stats,
                                     float* dgamma, float* dbeta, void* dx, long long M, int C, int nslots, double count,
-                                    mvit_stream_t stream) {
+                                    float drop_p, unsigned long long drop_seed, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0) return MVIT_EINVAL;
+  if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return MVIT_EINVAL;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(nblk(M * (C >> 3), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta,
-                     (bf16_t*)dx, M, C, nslots, count);
+                     (bf16_t*)dx, M, C, nslots, count, make_drop(drop_p, drop_seed));
   return MVIT_LAUNCH_CHECK();
 }
 

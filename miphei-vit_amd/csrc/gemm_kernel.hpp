@@ -784,8 +784,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
                 } else {
                   ld8f(p.aux ? (const float*)p.aux + (size_t)row * p.ldaux + col : Cf + o, r_, nv);
                 }
+                const float rsc = p.rowscale ? p.rowscale[row] : 1.f;   // DropPath factor of this row's sample (uniform branch)
 #pragma unroll
-                for (int e = 0; e < V; ++e) r_[e] += gam[e] * v[e];
+                for (int e = 0; e < V; ++e) r_[e] += rsc * gam[e] * v[e];
                 st8f(Cf + o, r_, nv);
               } else if constexpr (EPI == MVIT_EPI_PATCH) {
                 const int img = row / p.patch_P, pp = row - img * p.patch_P;

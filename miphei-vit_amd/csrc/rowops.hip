@@ -188,9 +188,11 @@ __global__ __launch_bounds__(64 * LNL_WAVES, 4) void ln_fwd_lora_kernel(const fl
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dh, const float* __restrict__ x,
                                                      const float* __restrict__ w, float* __restrict__ dx,
                                                      const float* __restrict__ gamma_next, bf16_t* __restrict__ dy,
-                                                     int M, int D, float eps, int accumulate) {
+                                                     int M, int D, float eps, int accumulate,
+                                                     const float* __restrict__ rowscale_next) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
+  const float rsn = rowscale_next ? rowscale_next[row] : 1.f;   // DropPath factor of the branch dy feeds (per sample)
   const int nv = D >> 2;
   const float4* xr = (const float4*)(x + (size_t)row * D);
   const uint2* gr = (const uint2*)(dh + (size_t)row * D);
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       if (dyr) {
         const float4 gm = ((const float4*)gamma_next)[idx];
         uint2 p;
-        p.x = pack2bf(r.x * gm.x, r.y * gm.y);
-        p.y = pack2bf(r.z * gm.z, r.w * gm.w);
+        p.x = pack2bf(r.x * gm.x * rsn, r.y * gm.y * rsn);
+        p.y = pack2bf(r.z * gm.z * rsn, r.w * gm.w * rsn);
         dyr[idx] = p;
       }
     }
@@ -360,15 +362,17 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
 }
 
 __global__ __launch_bounds__(256) void scale_cols_cast_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                              bf16_t* __restrict__ out, int M, int D) {
+                                                              bf16_t* __restrict__ out, int M, int D,
+                                                              const float* __restrict__ rowscale) {
   const long long nv = (long long)M * D / 4;
   const int dv = D >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
     const float4 v = ((const float4*)x)[i];
     const float4 g = ((const float4*)gamma)[i % dv];
+    const float rs = rowscale ? rowscale[i / dv] : 1.f;
     uint2 r;
-    r.x = pack2bf(v.x * g.x, v.y * g.y);
-    r.y = pack2bf(v.z * g.z, v.w * g.w);
+    r.x = pack2bf(v.x * g.x * rs, v.y * g.y * rs);
+    r.y = pack2bf(v.z * g.z * rs, v.w * g.w * rs);
     ((uint2*)out)[i] = r;
   }
 }
@@ -410,12 +414,13 @@ MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float
 }
 
 MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, float* dx, const float* gamma_next,
-                                void* dy, int M, int D, float eps, int accumulate, mvit_stream_t stream) {
+                                void* dy, int M, int D, float eps, int accumulate, const float* rowscale_next,
+                                mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
   if ((dy != nullptr) != (gamma_next != nullptr)) return MVIT_EINVAL;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, x, w, dx,
-                     gamma_next, (bf16_t*)dy, M, D, eps, accumulate);
+                     gamma_next, (bf16_t*)dy, M, D, eps, accumulate, rowscale_next);
   return MVIT_LAUNCH_CHECK();
 }
 
@@ -461,11 +466,12 @@ MVIT_API int mvit_cast_f32_bf16(const float* src, void* dst, long long n, mvit_s
   return MVIT_LAUNCH_CHECK();
 }
 
-MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out, int M, int D, mvit_stream_t stream) {
+MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out, int M, int D, const float* rowscale,
+                                  mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3)) return MVIT_EINVAL;
   hipLaunchKernelGGL(scale_cols_cast_kernel, dim3(nblocks((long long)M * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     gamma, (bf16_t*)out, M, D);
+                     gamma, (bf16_t*)out, M, D, rowscale);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -458,10 +458,28 @@ class HipEngine:
         w.dt = e(M, 2 * c.rank) if c.lora else None
 
     # ------------------------------------------------------------------ forward
+    def _drop_path_factors(self, w, c):
+        """Per-row DropPath factors of this step, [L, 2, M] f32 (branch 0 = attention, 1 = MLP), or None.
+
+        timm builds the blocks with ``drop_path = linspace(0, drop_path_rate, depth)[l]`` and applies, in train mode,
+        ``x = x + drop_path(ls(branch(norm(x))))`` with one Bernoulli(keep) draw per SAMPLE, kept samples scaled by 1/keep
+        (stochastic depth; reference: ``drop_path_rate=drop_rate`` at src/generators/unet.py:37 -> foundation_models.py:53-57).
+        The draws are torch RNG on the device (plumbing); the factors are consumed inside the residual epilogue of the proj / fc2
+        GEMMs and, for the gradient, inside the LayerNorm-backward kernel that emits the branch gradient."""
+        vit = self.model.encoder.vit
+        rate = float(getattr(vit, "drop_path_rate", 0.0) or 0.0)
+        if rate <= 0.0 or not vit.training:
+            return None
+        keep = 1.0 - torch.linspace(0.0, rate, c.L, device=w.tok.device).view(c.L, 1, 1)
+        draw = (torch.rand(c.L, 2, w.B, device=w.tok.device) < keep).float() / keep
+        return draw.repeat_interleave(c.ntok, dim=2).contiguous()
+
     def _encoder_fwd(self, w, x, train, pk, taps=None):
         """taps: {block index: bf16 [M, D] buffer} receives the residual stream after that block (forward_intermediates)"""
         c, fz = self._config(), self._ensure_frozen()
         B, M, D = w.B, w.M, c.D
+        w.dpath = self._drop_path_factors(w, c) if train else None
+        dp = w.dpath
         P = c.grid * c.grid
         ops.im2col_patch(x, w.patches, c.patch, c.grid)
         X = w.x_in[0]
@@ -485,11 +503,13 @@ class HipEngine:
                 ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
             ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale)
-            ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32)
+            ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32,
+                     rowscale=None if dp is None else dp[l, 0])
             ops.layernorm_fwd(xmid, b.n2w, b.n2b, w.h2, c.eps)
             ops.gemm(w.h2, b.wfc1, w.g, bias=b.bfc1, aux=(w.u[l] if train else None),
                      epi=EPI_SWIGLU if c.swiglu else EPI_GELU)
-            ops.gemm(w.g, b.wfc2, xout, bias=b.bfc2, gamma=b.ls2, aux=xmid, epi=EPI_RESID, flags=OUT_F32)
+            ops.gemm(w.g, b.wfc2, xout, bias=b.bfc2, gamma=b.ls2, aux=xmid, epi=EPI_RESID, flags=OUT_F32,
+                     rowscale=None if dp is None else dp[l, 1])
             if taps is not None and l in taps:
                 ops.cast_bf16(xout, taps[l])
         xf = w.x_in[c.L] if train else w.x_in[0]
@@ -739,16 +759,19 @@ class HipEngine:
         scale = c.Dh ** -0.5
         lsplit = max(1, min(512 // ((D + 127) // 128), (M + 255) // 256))
         last = fz.blocks[c.L - 1]
+        dp = getattr(w, "dpath", None)          # DropPath factors of the forward pass this backward belongs to
+        rs = (lambda l, br: None) if dp is None else (lambda l, br: dp[l, br])
         if from_tokens:
-            ops.layernorm_bwd(w.dtok, w.x_in[c.L], fz.nw, w.dx, last.ls2, w.dy, c.eps, accumulate=False)
+            ops.layernorm_bwd(w.dtok, w.x_in[c.L], fz.nw, w.dx, last.ls2, w.dy, c.eps, accumulate=False,
+                              rowscale_next=rs(c.L - 1, 1))
         else:
-            ops.scale_cols_cast(w.dx, last.ls2, w.dy)
+            ops.scale_cols_cast(w.dx, last.ls2, w.dy, rowscale=rs(c.L - 1, 1))
         for l in range(c.L - 1, -1, -1):
             b = fz.blocks[l]
             # MLP branch: dy = ls2 * dx
             ops.gemm(w.dy, b.t.wfc2, w.du, aux=w.u[l], epi=EPI_DSWIGLU if c.swiglu else EPI_DGELU)
             ops.gemm(w.du, b.t.wfc1, w.dh)
-            ops.layernorm_bwd(w.dh, w.x_mid[l], b.n2w, w.dx, b.ls1, w.dy, c.eps, accumulate=True)
+            ops.layernorm_bwd(w.dh, w.x_mid[l], b.n2w, w.dx, b.ls1, w.dy, c.eps, accumulate=True, rowscale_next=rs(l, 0))
             # attention branch: dy = ls1 * dx
             ops.gemm(w.dy, b.t.wproj, w.do)
             ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, w.dqkv, B, c.ntok, c.H, c.Dh, scale)
@@ -771,7 +794,8 @@ class HipEngine:
                 ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
                 if inject is not None:
                     inject(l - 1)
-                ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True)
+                ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True,
+                                  rowscale_next=rs(l - 1, 1))
 
     # ------------------------------------------------------------------ fused training step
     def loss_and_grad(self, out, target, marker_weights, lambda_factor):

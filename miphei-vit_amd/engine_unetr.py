@@ -9,6 +9,9 @@ Every layer of the reference graph maps onto kernels the MIPHEI-ViT path already
   * ConvTranspose2d(k2, s2): dense GEMM against the [4*Cout, Cin] repacked weight + `mvit_pixel_shuffle2x` into a channel slice of
     the concat buffer of the consuming stage (torch.cat never materialises); backward = inverse shuffle + dense / TN GEMMs
   * final conv1x1 and the fused per-marker heads.
+  * Dropout(drop_rate) behind every block's ReLU and DropPath(drop_rate) in the ViT blocks (the reference trains this baseline with
+    `model.dropout: 0.1`, configs/model/unet.yaml:2 -> generators/__init__.py:36): counter-based masks recomputed in the backward
+    kernels, per-sample DropPath factors inside the residual GEMM epilogues (engine._drop_path_factors).
 Activations are NHWC bf16, one buffer per graph node (kept for the backward pass).  Training goes through the autograd bridge
 (`generator(x)`, `loss.backward()`, any torch optimiser); the fused single-sequence step of MIPHEI-ViT is not built for this baseline.
 """
@@ -30,6 +33,7 @@ class UnetrEngine:
         self._enc = None
         self._ws = {}
         self._saved = None
+        self._drop_step = 0          # dropout masks are functions of (seed, step, layer, element): nothing is stored
 
     def invalidate(self):
         self._ws = {}
@@ -188,8 +192,11 @@ class UnetrEngine:
                         BN_MOM, bn_train)
         if bn_train:
             bn.num_batches_tracked += 1
-        ops.bn_relu_apply(pre, bnp.scale, bnp.shift, d, M, cout, cout, ld_dst)
-        st[name] = NS(wd=wd, gamma=gamma)
+        # nn.Dropout(drop_rate) behind the ReLU of every Conv2DBlock / Deconv2DBlock (reference unet.py:441-519), train mode only
+        drop_p = float(self.model.decoder.drop_rate or 0.0) if bn_train else 0.0
+        drop_seed = (st["_seed"] + 0x632BE59BD9B4E019 * (1 + len(st))) & 0xFFFFFFFFFFFFFFFF if drop_p > 0 else 0
+        ops.bn_relu_apply(pre, bnp.scale, bnp.shift, d, M, cout, cout, ld_dst, drop_p=drop_p, drop_seed=drop_seed)
+        st[name] = NS(wd=wd, gamma=gamma, drop_p=drop_p, drop_seed=drop_seed)
 
     def _convT_fwd(self, w, rec, st):
         _, name, src, H, ct, dst, off, _ = rec
@@ -246,7 +253,8 @@ class UnetrEngine:
             ops.resample2d(we.tap16[i][c.prefix:], w.buf[f"feat{i}"], ty, ty, B=B, h=c.grid, w=c.grid, H=G, W=G, C=D, ld_src=D,
                            ld_dst=D, src_bstride=c.ntok * D, dst_bstride=G * G * D)
         ops.image_to_nhwc(x, w.buf["img8"], 8, nzero=5)
-        st = {}
+        self._drop_step += 1
+        st = {"_seed": (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF}
         for rec in w.layers:
             if rec[0] == "conv":
                 self._conv_fwd(w, rec, bn_train, st)
@@ -399,7 +407,7 @@ class UnetrEngine:
         sb.zero_()
         dgam, dbet = torch.zeros(cout, device=a.device), torch.zeros(cout, device=a.device)
         ops.bn_relu_bwd(dy, dd.shape[-1], pre, bnp.scale, bnp.shift, bnp.mean, bnp.rstd, st[name].gamma, sb, dgam, dbet, dpre, M, cout,
-                        NSLOTS)
+                        NSLOTS, drop_p=st[name].drop_p, drop_seed=st[name].drop_seed)
         grads[id(bn.weight)], grads[id(bn.bias)] = dgam, dbet
         if conv.bias is not None:
             grads[id(conv.bias)] = torch.zeros_like(conv.bias)      # bias in front of a train-mode BatchNorm: zero gradient

@@ -25,7 +25,7 @@ def get_generator(model_name, img_size, nc_in, nc_out, cfg):
         return get_vitmatte(_cfg_get(cfg, "model.encoder.encoder_name"), img_size, nc_out, use_lora=True,
                             ckpt_path=ckpt_path, pretrained=pretrained)
     if model_name.startswith("unet"):
-        # UNETR baseline (reference src/generators/__init__.py:25-41); forward only on this path so far
+        # UNETR baseline (reference src/generators/__init__.py:25-41): forward, backward, Dropout / DropPath
         if _cfg_get(cfg, "train.foreground_head", False):
             raise NotImplementedError
         from .unet import Unet

@@ -159,8 +159,11 @@ def _load_checkpoint(model, ckpt_path, img_size):
     model.load_state_dict(sd)
 
 
-def _build(img_size, pretrained, ckpt_path, name, **kw):
+def _build(img_size, pretrained, ckpt_path, name, drop_path_rate=0., **kw):
     model = VisionTransformer(img_size=img_size, **kw)
+    # stochastic depth of timm's blocks (linspace(0, rate, depth) per block, per-sample Bernoulli in train mode): the engine draws
+    # the factors per step and applies them inside the residual epilogues (engine._drop_path_factors)
+    model.drop_path_rate = float(drop_path_rate or 0.)
     if ckpt_path is not None:
         _load_checkpoint(model, ckpt_path, img_size)
     elif pretrained and os.environ.get("MIPHEI_RANDOM_INIT", "0") != "1":
@@ -173,29 +176,29 @@ def _build(img_size, pretrained, ckpt_path, name, **kw):
 def hoptimus0(img_size, pretrained=True, ckpt_path=None, drop_path_rate=0., global_pool=""):
     """H-Optimus-0 = vit_giant_patch14_reg4_dinov2 (reference foundation_models.py:50-69)."""
     return _build(img_size, pretrained, ckpt_path, "hoptimus0", patch_size=14, embed_dim=1536, depth=40, num_heads=24,
-                  mlp="swiglu", hidden=8192, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+                  mlp="swiglu", hidden=8192, reg_tokens=4, init_values=1e-5, global_pool=global_pool, drop_path_rate=drop_path_rate)
 
 
 def tiny_gelu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
     """BASELINE.json config 1 'Tiny-ViT (2 layers, 64-d)': patch16 D64 L2 H4 GELU (not in the reference registry)."""
     return _build(img_size, False, ckpt_path, "tiny", patch_size=16, embed_dim=64, depth=2, num_heads=4, mlp="gelu",
-                  hidden=256, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+                  hidden=256, reg_tokens=4, init_values=1e-5, global_pool=global_pool, drop_path_rate=drop_path_rate)
 
 
 def tiny_swiglu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
     return _build(img_size, False, ckpt_path, "tiny_swiglu", patch_size=14, embed_dim=96, depth=2, num_heads=3,
-                  mlp="swiglu", hidden=512, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+                  mlp="swiglu", hidden=512, reg_tokens=4, init_values=1e-5, global_pool=global_pool, drop_path_rate=drop_path_rate)
 
 
 def tiny4_gelu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
     """depth-4 variant of `tiny` (the UNETR baseline needs >= 4 blocks)"""
     return _build(img_size, False, ckpt_path, "tiny4", patch_size=16, embed_dim=64, depth=4, num_heads=4, mlp="gelu",
-                  hidden=256, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+                  hidden=256, reg_tokens=4, init_values=1e-5, global_pool=global_pool, drop_path_rate=drop_path_rate)
 
 
 def tiny4_swiglu(img_size, pretrained=False, ckpt_path=None, drop_path_rate=0., global_pool=""):
     return _build(img_size, False, ckpt_path, "tiny4_swiglu", patch_size=14, embed_dim=96, depth=4, num_heads=3,
-                  mlp="swiglu", hidden=512, reg_tokens=4, init_values=1e-5, global_pool=global_pool)
+                  mlp="swiglu", hidden=512, reg_tokens=4, init_values=1e-5, global_pool=global_pool, drop_path_rate=drop_path_rate)
 
 
 FOUNDATION_MODEL_REGISTRY = {

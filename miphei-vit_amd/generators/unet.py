@@ -114,8 +114,8 @@ class Unet(nn.Module):
         super().__init__()
         if encoder_name not in FOUNDATION_MODEL_REGISTRY:
             raise NotImplementedError(f"encoder '{encoder_name}': only the ViT registry encoders run on the MI355X path")
-        if drop_rate:
-            raise NotImplementedError("dropout / drop-path > 0 is outside the MI355X path (0 in every shipped config)")
+        if not 0.0 <= float(drop_rate) < 1.0:
+            raise ValueError("drop_rate must be in [0, 1)")
         if decoder_out_channels != 32 or not head_use_attention or classes > 16:
             raise NotImplementedError("heads: 32-channel decoder output, attention heads, at most 16 markers")
         self.encoder = ViTPyramidEncoder(img_size, encoder_name, ckpt_path=encoder_weights, drop_path_rate=drop_rate,

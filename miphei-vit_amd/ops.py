@@ -46,7 +46,7 @@ def _chk_bf16(t, name):
 
 def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=None, b2=None, K2=0, bias=None,
          gamma=None, aux=None, ldaux=0, pos=None, stats=None, nslots=0, epi=EPI_STORE, flags=0, ksplit=1,
-         amode=A_DENSE, conv=None, patch=None):
+         amode=A_DENSE, conv=None, patch=None, rowscale=None):
     """C[M,N] = A[M,K] @ B[N,K]^T (+ A2 @ B2^T) with a fused epilogue (mvit_gemm_bf16)."""
     _chk_bf16(a, "A")
     _chk_bf16(b, "B")
@@ -82,6 +82,9 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     if stats is not None:
         assert stats.dtype == torch.float64
         g.stats, g.nslots = stats.data_ptr(), nslots
+    if rowscale is not None:
+        assert rowscale.dtype == torch.float32 and epi == EPI_RESID and rowscale.numel() >= g.M
+        g.rowscale = rowscale.data_ptr()
     if patch is not None:
         g.patch_P, g.patch_ntok, g.patch_prefix = patch
     g.epi, g.flags, g.ksplit, g.amode = epi, flags, ksplit, amode
@@ -156,9 +159,10 @@ def unpack_conv3x3_wgrad(dWt, dW, cin_pad, rot=0, accumulate=False):
     _call("mvit_unpack_conv3x3_wgrad", _p(dWt), _p(dW), cout, cin, cin_pad, rot, int(accumulate))
 
 
-def layernorm_bwd(dh, x, w, dx, gamma_next=None, dy=None, eps=1e-6, accumulate=True):
+def layernorm_bwd(dh, x, w, dx, gamma_next=None, dy=None, eps=1e-6, accumulate=True, rowscale_next=None):
     M, D = x.shape
-    _call("mvit_layernorm_bwd", _p(dh), _p(x), _p(w), _p(dx), _p(gamma_next), _p(dy), M, D, eps, int(accumulate))
+    _call("mvit_layernorm_bwd", _p(dh), _p(x), _p(w), _p(dx), _p(gamma_next), _p(dy), M, D, eps, int(accumulate),
+          _p(rowscale_next))
 
 
 def skinny_xw(X, W, out, *, ldx=None, ldw=None, ldo=None, M=None, K=None, R=None):
@@ -192,9 +196,9 @@ def cast_bf16(src, dst):
     return dst
 
 
-def scale_cols_cast(x, gamma, out):
+def scale_cols_cast(x, gamma, out, rowscale=None):
     M, D = x.shape
-    _call("mvit_scale_cols_cast", _p(x), _p(gamma), _p(out), M, D)
+    _call("mvit_scale_cols_cast", _p(x), _p(gamma), _p(out), M, D, _p(rowscale))
     return out
 
 
@@ -227,15 +231,33 @@ def bn_finalize(stats, gamma, beta, rmean, rvar, scale, shift, mean, rstd, C_, n
           _p(rstd), C_, nslots, float(count), eps, momentum, int(training))
 
 
-def bn_relu_apply(x, scale, shift, out, M, C_, ld_x, ld_out):
-    _call("mvit_bn_relu_apply", _p(x), _p(scale), _p(shift), _p(out), M, C_, ld_x, ld_out)
+def bn_relu_apply(x, scale, shift, out, M, C_, ld_x, ld_out, drop_p=0.0, drop_seed=0):
+    """out = dropout(relu(x*scale + shift)); drop_p > 0: counter-based mask from (drop_seed, element index), see the header"""
+    _call("mvit_bn_relu_apply", _p(x), _p(scale), _p(shift), _p(out), M, C_, ld_x, ld_out, float(drop_p), int(drop_seed))
 
 
-def bn_relu_bwd(dy, ld_dy, x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta, dx, M, C_, nslots):
+def bn_relu_bwd(dy, ld_dy, x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta, dx, M, C_, nslots, drop_p=0.0, drop_seed=0):
     _call("mvit_bn_relu_bwd_reduce", _p(dy), ld_dy, _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), M, C_,
-          nslots)
+          nslots, float(drop_p), int(drop_seed))
     _call("mvit_bn_relu_bwd_apply", _p(dy), ld_dy, _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(gamma), _p(stats),
-          _p(dgamma), _p(dbeta), _p(dx), M, C_, nslots, float(M))
+          _p(dgamma), _p(dbeta), _p(dx), M, C_, nslots, float(M), float(drop_p), int(drop_seed))
+
+
+def dropout_keep_mask(seed, n, p):
+    """Host restatement of the kernels' counter-based dropout mask: float multipliers (0 or 1/(1-p')) of elements 0..n-1."""
+    import numpy as np
+    thresh = int(p * 65536.0 + 0.5) if p > 0 else 0
+    if thresh == 0:
+        return torch.ones(n)
+    e = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (e >> np.uint64(2)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    field = (z >> (np.uint64(16) * (e & np.uint64(3)))) & np.uint64(0xffff)
+    keep = field >= np.uint64(thresh)
+    return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - thresh / 65536.0))
 
 
 def pack_conv3x3_weights(W, wk, wd, rot=0):

@@ -5,7 +5,9 @@ Reference: src/generators/unet.py -- `Unet` :13-92 (ViTPyramidEncoder + Decoder 
 `ViTPyramidEncoder` :116-171 (timm `forward_intermediates(indices, norm=False, output_fmt='NCHW')` at four depths, LoRA on q/v),
 `ViTFeatureUpsampler` :174-236 (conv stem on the image + nearest re-grid + Deconv2DBlock pyramids), `Decoder` :288-404,
 `Conv2DBlock` :441-474 (conv3x3 with bias -> BatchNorm -> ReLU), `Deconv2DBlock` :477-519 (ConvTranspose2d k2 s2 -> conv3x3 ->
-BatchNorm -> ReLU), `initialize_decoder_head` :522-531.  Dropout rate is 0 in every shipped config (identity).
+BatchNorm -> ReLU -> Dropout), `initialize_decoder_head` :522-531.  The reference trains this baseline with `model.dropout: 0.1`
+(configs/model/unet.yaml:2): nn.Dropout behind every block's ReLU and timm DropPath in the ViT blocks.  Both are random; the
+restatement takes the masks as inputs (`drop=` hooks) so that a test can feed it the masks the HIP kernels used.
 State-dict keys follow the reference modules (encoder.model.* = the timm ViT, encoder.feature_upsampler.*, decoder.*,
 segmentation_head_<i>.*).
 """
@@ -89,25 +91,32 @@ def unetr_state_shapes(cfg: ViTConfig, img: int, nc_out: int, lora: bool = True)
     return s
 
 
+_DROP = None   # test hook: callable(block prefix, activation NCHW) -> multiplier tensor (nn.Dropout mask / (1-p)), or None
+
+
+def _dropout(pre, y):
+    return y if _DROP is None else y * _DROP(pre, y)
+
+
 def conv_block(p, pre, x, training, new_stats=None):
     x = F.conv2d(x, p[pre + "block.0.weight"], p[pre + "block.0.bias"], padding=1)
-    return F.relu(_bn(p, pre + "block.1.", x, training, new_stats))
+    return _dropout(pre, F.relu(_bn(p, pre + "block.1.", x, training, new_stats)))
 
 
 def deconv_block(p, pre, x, training, new_stats=None):
     x = F.conv_transpose2d(x, p[pre + "block.0.weight"], p[pre + "block.0.bias"], stride=2)
     x = F.conv2d(x, p[pre + "block.1.weight"], p[pre + "block.1.bias"], padding=1)
-    return F.relu(_bn(p, pre + "block.2.", x, training, new_stats))
+    return _dropout(pre, F.relu(_bn(p, pre + "block.2.", x, training, new_stats)))
 
 
-def vit_intermediates(p, x, cfg: ViTConfig, prefix: str, lora: bool):
+def vit_intermediates(p, x, cfg: ViTConfig, prefix: str, lora: bool, drop_path=None):
     """timm 1.0.15 VisionTransformer.forward_intermediates(indices=extract_layers, norm=False, output_fmt='NCHW',
     intermediates_only=True): block outputs without the prefix tokens, as [B, D, g, g]."""
     t = vit_embed(p, x, cfg, prefix)
     take, outs = extract_layers(cfg.depth), []
     B, g = x.shape[0], x.shape[-1] // cfg.patch
     for i in range(cfg.depth):
-        t = vit_block(p, f"{prefix}blocks.{i}.", t, cfg, lora)
+        t = vit_block(p, f"{prefix}blocks.{i}.", t, cfg, lora, None if drop_path is None else drop_path[i])
         if i in take:
             outs.append(t[:, cfg.num_prefix:].reshape(B, g, g, cfg.dim).permute(0, 3, 1, 2))
     return outs
@@ -155,10 +164,20 @@ def unetr_decoder(p, z, training, new_stats=None, prefix="decoder."):
 
 
 def unetr_forward(p: dict, x: torch.Tensor, cfg: ViTConfig, nc_out: int, training: bool = False, lora: bool = True,
-                  new_stats: dict | None = None):
-    """Unet.forward (unet.py:83-92) with Tanh heads."""
+                  new_stats: dict | None = None, drop=None, drop_path=None):
+    """Unet.forward (unet.py:83-92) with Tanh heads.  drop: callable(block prefix, activation) -> dropout multipliers;
+    drop_path: [L, 2, B] per-sample DropPath factors (both None = eval mode / rate 0)."""
+    global _DROP
+    _DROP = drop
+    try:
+        return _unetr_forward(p, x, cfg, nc_out, training, lora, new_stats, drop_path)
+    finally:
+        _DROP = None
+
+
+def _unetr_forward(p, x, cfg, nc_out, training, lora, new_stats, drop_path):
     img = x.shape[-1]
-    feats = vit_intermediates(p, x, cfg, "encoder.model.", lora)
+    feats = vit_intermediates(p, x, cfg, "encoder.model.", lora, drop_path)
     z = feature_upsampler(p, x, feats, cfg, img, training, new_stats)
     f = unetr_decoder(p, z, training, new_stats)
     return torch.cat([segmentation_head(p, f"segmentation_head_{h}.", f, training, new_stats) for h in range(nc_out)], 1)

@@ -104,8 +104,9 @@ def lora_qkv(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor, Aq: torch.Tensor
     return torch.cat([qkv[..., :D] + dq, qkv[..., D : 2 * D], qkv[..., 2 * D :] + dv], dim=-1)
 
 
-def vit_block(p: dict, pre: str, x: torch.Tensor, cfg: ViTConfig, lora: bool) -> torch.Tensor:
-    """One timm Block: x + ls1*attn(norm1 x); x + ls2*mlp(norm2 x)  (App. A)."""
+def vit_block(p: dict, pre: str, x: torch.Tensor, cfg: ViTConfig, lora: bool, drop_path=None) -> torch.Tensor:
+    """One timm Block: x + dp1(ls1*attn(norm1 x)); x + dp2(ls2*mlp(norm2 x))  (App. A).  drop_path: None (eval / rate 0) or a [2, B]
+    tensor of the per-sample DropPath factors (0 or 1/keep) of the attention and MLP branch (timm.layers.DropPath, train mode)."""
     B, N, D = x.shape
     H, Dh = cfg.heads, D // cfg.heads
     h = F.layer_norm(x, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps)
@@ -120,7 +121,8 @@ def vit_block(p: dict, pre: str, x: torch.Tensor, cfg: ViTConfig, lora: bool) ->
     att = att.softmax(dim=-1)
     o = (att @ v).transpose(1, 2).reshape(B, N, D)
     o = F.linear(o, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"])
-    x = x + p[pre + "ls1.gamma"] * o
+    o = p[pre + "ls1.gamma"] * o
+    x = x + (o if drop_path is None else o * drop_path[0].view(B, 1, 1))
     h = F.layer_norm(x, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps)
     u = F.linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])
     if cfg.mlp == "swiglu":
@@ -129,7 +131,8 @@ def vit_block(p: dict, pre: str, x: torch.Tensor, cfg: ViTConfig, lora: bool) ->
     else:
         g = F.gelu(u)  # erf form
     y = F.linear(g, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
-    return x + p[pre + "ls2.gamma"] * y
+    y = p[pre + "ls2.gamma"] * y
+    return x + (y if drop_path is None else y * drop_path[1].view(B, 1, 1))
 
 
 def vit_embed(p: dict, x: torch.Tensor, cfg: ViTConfig, prefix: str) -> torch.Tensor:

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     body = hdr[hdr.index("typedef struct mvit_gemm_args"):hdr.index("} mvit_gemm_args;")]
     n_ptr = len(re.findall(r"\*\s*\w+\s*[;,]", body))
     n_int = sum(len(l.replace("int", "", 1).split(",")) for l in body.splitlines() if l.strip().startswith("int "))
-    assert (n_ptr, n_int) == (10, 25)
+    assert (n_ptr, n_int) == (11, 25)
     assert ctypes.sizeof(_lib.GemmArgs) == n_ptr * 8 + ((n_int * 4 + 7) // 8) * 8
 
 
@@ -170,12 +170,29 @@ def test_checkpoint_prune_load_validate(tmp_path):
     assert sorted(get_generator_state_dict(lightning)) == sorted(src.state_dict())
 
 
-def test_pos_embed_resize_on_load():
+def test_pos_embed_resize_on_load_values():
+    """Load-time re-grid of a 224-pixel checkpoint (16x16 table) to the 256 / 512-pixel grids, and a down-sampling case, value by
+    value against the independent restatement of timm's resample_abs_pos_embed (bicubic, antialias) in oracle/posembed.py."""
+    import torch.nn.functional as F
+    from oracle.posembed import resample_abs_pos_embed
     from miphei_vit_amd.generators.foundation_models import VisionTransformer, resize_pos_embed_statedict
-    m = VisionTransformer(img_size=256, patch_size=14, embed_dim=96, depth=1, num_heads=3, mlp="swiglu", hidden=512)
-    sd = {"pos_embed": torch.randn(1, 16 * 16, 96)}   # checkpoint trained at 224 (16x16 grid)
-    out = resize_pos_embed_statedict(sd, m, 256)
-    assert out["pos_embed"].shape == (1, 18 * 18, 96)
+    for img, old in ((256, 16), (512, 16), (128, 16)):
+        m = VisionTransformer(img_size=img, patch_size=14, embed_dim=96, depth=1, num_heads=3, mlp="swiglu", hidden=512)
+        g = m.patch_embed.grid_size
+        pe = torch.randn(1, old * old, 96, generator=torch.Generator().manual_seed(img))
+        out = resize_pos_embed_statedict({"pos_embed": pe.clone()}, m, img)["pos_embed"]
+        assert out.shape == (1, g[0] * g[1], 96) and out.dtype == pe.dtype
+        want = resample_abs_pos_embed(pe.numpy(), (old, old), tuple(g))
+        assert float((out - torch.from_numpy(want)).abs().max()) < 1e-5      # f32 filter weights vs the f64 restatement
+        # the antialias flag is part of the contract: plain bicubic (a = -0.75, no low-pass) gives a different table
+        plain = F.interpolate(pe.reshape(1, old, old, 96).permute(0, 3, 1, 2), size=tuple(g), mode="bicubic")
+        assert float((plain.permute(0, 2, 3, 1).reshape(1, -1, 96) - out).abs().max()) > 1e-3
+    # same grid: untouched; a checkpoint carrying a class-token slot loses it
+    m = VisionTransformer(img_size=224, patch_size=14, embed_dim=96, depth=1, num_heads=3, mlp="swiglu", hidden=512)
+    pe = torch.randn(1, 256, 96)
+    assert torch.equal(resize_pos_embed_statedict({"pos_embed": pe}, m, 224)["pos_embed"], pe)
+    pe1 = torch.randn(1, 257, 96)
+    assert torch.equal(resize_pos_embed_statedict({"pos_embed": pe1}, m, 224)["pos_embed"], pe1[:, 1:])
 
 
 _DDP_WORKER = r'''

@@ -202,3 +202,104 @@ def test_unetr_half_eval_and_errors(golden_dir):
         get_generator("unet_lora", 128, 3, 3, conf)
     with pytest.raises(NotImplementedError):
         Unet(128, "restnet50_lunit_swav", classes=3, pretrained=False)
+
+
+def _oracle_prefix(layer):
+    """engine layer name -> block prefix of the reference state dict"""
+    up = "encoder.feature_upsampler."
+    if layer in ("s0", "s1"):
+        return f"{up}convsteam.{layer[1]}."
+    if layer.startswith("u"):                      # "u0.2.c": upsampler0, Deconv2DBlock 2 (its conv part)
+        a, k, _ = layer[1:].split(".")
+        return f"{up}upsampler{a}.{k}."
+    d, k = layer[1:].split(".")                    # "d3.1": decoder3_upsampler.1 / "d0.k": decoder0_header.k
+    return f"decoder.decoder{d}_" + ("header" if d == "0" else "upsampler") + f".{k}."
+
+
+@pytest.mark.gpu
+def test_unetr_train_mode_dropout_and_drop_path_match_oracle_with_the_same_masks(golden_dir):
+    """The reference trains the UNETR baseline with model.dropout = 0.1 (configs/model/unet.yaml:2): nn.Dropout behind every block's
+    ReLU, timm DropPath in the ViT blocks.  The HIP masks are counter-based (seed, layer, element) and the DropPath factors are kept
+    with the saved activations, so the oracle can be run with exactly the masks the kernels applied: outputs, loss and gradients
+    must then agree as in the deterministic tests.  Eval mode is unaffected by the rate."""
+    from oracle import synth_batch, weighted_mse_loss
+    from oracle.model import orion_marker_weights
+    from oracle.unetr import unetr_forward
+    from miphei_vit_amd import ops
+    from miphei_vit_amd.generators.unet import Unet
+    g, cfg, p, img, nc, B, seed = _load(golden_dir, "tiny4_swiglu_p14_128")
+    rate = 0.3
+    torch.manual_seed(1234)
+    model = Unet(img, str(g["cfg"]), use_lora=True, classes=nc, pretrained=False, drop_rate=rate)
+    model.load_state_dict(p)
+    model = model.cuda().train()
+    x, y = synth_batch(seed, B, img, nc)
+    w = orion_marker_weights(16)[:nc]
+    out = model(x.cuda())
+    loss = weighted_mse_loss(y.cuda(), out, w.cuda())
+    loss.backward()
+    sv = model._engine._saved
+    dpath = sv.we.dpath                                        # [L, 2, M] per-row factors of this step
+    assert dpath is not None and dpath.shape[:2] == (cfg.depth, 2)
+    dp = dpath[:, :, ::cfg.tokens(img)].cpu()                  # one factor per sample
+    assert torch.equal(dpath.view(cfg.depth, 2, B, -1)[..., :1].expand(-1, -1, -1, cfg.tokens(img)).reshape(dpath.shape), dpath)
+    keep_last = 1.0 - rate
+    assert float(dp[0].min()) == 1.0                           # block 0: rate 0 (linspace(0, rate, depth))
+    assert set(dp[-1].flatten().tolist()) <= {0.0, pytest.approx(1.0 / keep_last)}
+    seeds = {_oracle_prefix(k): (v.drop_seed, v.drop_p) for k, v in sv.st.items() if hasattr(v, "drop_seed")}
+    assert len(seeds) == 17 and len({s for s, _ in seeds.values()}) == 17 and all(abs(pp - rate) < 1e-9 for _, pp in seeds.values())
+    zeros = []
+
+    def drop(prefix, act):
+        s, pp = seeds[prefix]
+        Bc, C, H, W = act.shape
+        m = ops.dropout_keep_mask(s, Bc * H * W * C, pp).view(Bc, H, W, C).permute(0, 3, 1, 2)
+        zeros.append(float((m == 0).float().mean()))
+        return m
+
+    train_keys = [k for k, v in model.named_parameters() if v.requires_grad]
+    q = {k: (v.clone().requires_grad_(True) if k in train_keys else v.clone()) for k, v in p.items()}
+    o_ref = unetr_forward(q, x, cfg, nc, training=True, drop=drop, drop_path=dp)
+    l_ref = weighted_mse_loss(y, o_ref, w)
+    l_ref.backward()
+    assert all(abs(z - rate) < 0.02 for z in zeros), zeros       # the masks drop ~rate of the elements
+    rel = ((out.detach().float().cpu() - o_ref.detach()) ** 2).sum(dim=(0, 2, 3)) / (o_ref.detach() ** 2).sum(dim=(0, 2, 3))
+    assert float(rel.max()) < 2e-3, rel
+    assert abs(float(loss) - float(l_ref)) < 3e-3 * abs(float(l_ref))
+    named = dict(model.named_parameters())
+    gnorm = float(torch.cat([q[k].grad.flatten().double() for k in train_keys if q[k].grad is not None]).norm())
+    worst = {}
+    for k in train_keys:
+        gr = q[k].grad
+        if gr is None or float(gr.double().norm()) < 1e-3 * gnorm:
+            continue
+        e = _rel(named[k].grad.cpu(), gr)
+        if e > 0.06:
+            worst[k] = round(e, 4)
+    assert not worst, sorted(worst.items(), key=lambda kv: -kv[1])[:10]
+    # a second step draws different masks; eval mode ignores the rate
+    out2 = model(x.cuda())
+    assert float((out2 - out).abs().max()) > 1e-3
+    model.eval()
+    ref_model = Unet(img, str(g["cfg"]), use_lora=True, classes=nc, pretrained=False, drop_rate=0.0)
+    ref_model.load_state_dict(model.state_dict())
+    ref_model = ref_model.cuda().eval()
+    with torch.no_grad():
+        assert torch.equal(model(x.cuda()), ref_model(x.cuda()))
+
+
+def test_get_generator_unet_lora_accepts_the_shipped_dropout():
+    """`run.py +default_configs=unetr` composes model.dropout = 0.1 (as the reference's model/unet.yaml): the generator must build."""
+    import os
+    from miphei_vit_amd.config import compose
+    from miphei_vit_amd.generators import get_generator
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = compose(os.path.join(root, "configs"), ["+default_configs=unetr", "++model.encoder.encoder_name=tiny4",
+                                                  "++model.encoder.pretrained=false"])
+    assert cfg.model.dropout == 0.1 and cfg.model.model_name == "unet_lora"
+    gen = get_generator(cfg.model.model_name, 128, 3, 3, cfg)
+    assert gen.decoder.drop_rate == 0.1 and gen.encoder.model.drop_path_rate == 0.1
+    assert any(isinstance(m, torch.nn.Dropout) and m.p == 0.1 for m in gen.modules())
+    with pytest.raises(ValueError):
+        from miphei_vit_amd.generators.unet import Unet
+        Unet(128, "tiny4", classes=3, pretrained=False, drop_rate=1.0)
