@@ -245,7 +245,7 @@ def test_unetr_train_mode_dropout_and_drop_path_match_oracle_with_the_same_masks
     assert torch.equal(dpath.view(cfg.depth, 2, B, -1)[..., :1].expand(-1, -1, -1, cfg.tokens(img)).reshape(dpath.shape), dpath)
     keep_last = 1.0 - rate
     assert float(dp[0].min()) == 1.0                           # block 0: rate 0 (linspace(0, rate, depth))
-    assert set(dp[-1].flatten().tolist()) <= {0.0, pytest.approx(1.0 / keep_last)}
+    assert all(v == 0.0 or abs(v - 1.0 / keep_last) < 1e-6 for v in dp[-1].flatten().tolist())
     seeds = {_oracle_prefix(k): (v.drop_seed, v.drop_p) for k, v in sv.st.items() if hasattr(v, "drop_seed")}
     assert len(seeds) == 17 and len({s for s, _ in seeds.values()}) == 17 and all(abs(pp - rate) < 1e-9 for _, pp in seeds.values())
     zeros = []
@@ -258,25 +258,34 @@ def test_unetr_train_mode_dropout_and_drop_path_match_oracle_with_the_same_masks
         return m
 
     train_keys = [k for k, v in model.named_parameters() if v.requires_grad]
-    q = {k: (v.clone().requires_grad_(True) if k in train_keys else v.clone()) for k, v in p.items()}
-    o_ref = unetr_forward(q, x, cfg, nc, training=True, drop=drop, drop_path=dp)
-    l_ref = weighted_mse_loss(y, o_ref, w)
-    l_ref.backward()
+
+    def ref(autocast):
+        q = {k: (v.clone().requires_grad_(True) if k in train_keys else v.clone()) for k, v in p.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            o = unetr_forward(q, x, cfg, nc, training=True, drop=drop, drop_path=dp)
+        l = weighted_mse_loss(y, o.float(), w)
+        l.backward()
+        return o.detach().float(), float(l), {k: q[k].grad for k in train_keys}
+
+    o_ref, l_ref, gref = ref(False)
+    _, _, gac = ref(True)                                        # the same arithmetic in the reference's bf16-mixed mode
     assert all(abs(z - rate) < 0.02 for z in zeros), zeros       # the masks drop ~rate of the elements
-    rel = ((out.detach().float().cpu() - o_ref.detach()) ** 2).sum(dim=(0, 2, 3)) / (o_ref.detach() ** 2).sum(dim=(0, 2, 3))
+    rel = ((out.detach().float().cpu() - o_ref) ** 2).sum(dim=(0, 2, 3)) / (o_ref ** 2).sum(dim=(0, 2, 3))
     assert float(rel.max()) < 2e-3, rel
-    assert abs(float(loss) - float(l_ref)) < 3e-3 * abs(float(l_ref))
+    assert abs(float(loss) - l_ref) < 3e-3 * abs(l_ref)
     named = dict(model.named_parameters())
-    gnorm = float(torch.cat([q[k].grad.flatten().double() for k in train_keys if q[k].grad is not None]).norm())
+    gnorm = float(torch.cat([v.flatten().double() for v in gref.values() if v is not None]).norm())
     worst = {}
     for k in train_keys:
-        gr = q[k].grad
+        gr = gref[k]
         if gr is None or float(gr.double().norm()) < 1e-3 * gnorm:
             continue
-        e = _rel(named[k].grad.cpu(), gr)
-        if e > 0.06:
-            worst[k] = round(e, 4)
-    assert not worst, sorted(worst.items(), key=lambda kv: -kv[1])[:10]
+        e_hip, e_ac = _rel(named[k].grad.cpu(), gr), _rel(gac[k], gr)
+        # yardstick of the deterministic test: no noisier than 1.25x bf16 autocast; a wrong mask in a backward kernel would show
+        # as an error of the order of the rate (0.3), far above either
+        if e_hip > max(1.25 * e_ac, 0.02):
+            worst[k] = (round(e_hip, 4), round(e_ac, 4))
+    assert not worst, sorted(worst.items(), key=lambda kv: -kv[1][0])[:10]
     # a second step draws different masks; eval mode ignores the rate
     out2 = model(x.cuda())
     assert float((out2 - out).abs().max()) > 1e-3
