@@ -225,6 +225,23 @@ MVIT_API int mvit_pix_metrics_update(const float* pred, const float* target, dou
                                      long long scratch_bytes, int B, int C, int H, int W, float lo, float hi,
                                      mvit_stream_t stream);
 
+/* ---------------------------------------------------------------- direct 3x3 convolution with LDS-staged input tiles */
+/* Y[b,y,x,0..Cout) = sum_{ky,kx,c} X[b, y+ky-1, x+kx-1, c] * Wp[(ky,kx)][n][c]   (stride 1, zero padding 1, NHWC bf16, f32 accumulate)
+ * for the few-channel full-resolution layers: the conv of the last Fusion_Block (src/generators/mipheivit.py:76-93, 67 -> 32
+ * channels at 256 x 256) and, on weights packed with mode 1, its input gradient.  A persistent block stages (8+2) x (32+2) pixel
+ * halo tiles in LDS by DMA (double-buffered) and reads all nine taps from there.  stats (nullable): [nslots][2][Cout] f64 sums of
+ * the f32 results and of their squares (BatchNorm statistics, as MVIT_EPI_STATS).
+ * Cin_pad = channels read per pixel (multiple of 8; pixel stride ldx >= Cin_pad), supported (Cin_pad, Cout): see
+ * mvit_conv3x3_direct_supported. */
+MVIT_API int mvit_conv3x3_direct_supported(int Cin_pad, int Cout);
+MVIT_API int mvit_conv3x3_direct(const void* X, const void* Wp, void* Y, double* stats, int nslots, int B, int H, int W, int Cin_pad,
+                                 int ldx, int Cout, int ldy, mvit_stream_t stream);
+/* nn.Conv2d weight [Cout,Cin,3,3] f32 -> Wp [9][n_out][ceil16(k_pad) + 8] bf16 (zero padded).
+ * mode 0 (forward, k_in = Cin, n_out >= Cout):  Wp[tap][n][c]   = W[n][(c+rot) % Cin][ky][kx]
+ * mode 1 (input gradient, k_in = Cout, n_out <= Cin input channels wanted):  Wp[tap][ci][co] = W[co][(ci+rot) % Cin][2-ky][2-kx] */
+MVIT_API int mvit_pack_conv3x3_direct(const float* W, void* out, int Cout, int Cin, int n_out, int k_in, int k_pad, int rot,
+                                      int mode, mvit_stream_t stream);
+
 /* ---------------------------------------------------------------- per-step operand packs of the trainable tensors */
 /* LoRA adapters (src/generators/lora.py:8-33) from the flat f32 parameter region `lora` = L x [Aq [D,r] | Bq [r,D] | Av | Bv]
  * to the bf16 operands of the kernels, R2 = 2r: AcatT [L,R2,D], Acat [L,D,R2] (may be NULL), B2 [L,3D,R2] (alpha*B on the q

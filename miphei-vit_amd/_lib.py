@@ -46,6 +46,9 @@ SIGNATURES = {
     "mvit_gemm_tn_bf16": [C.POINTER(GemmTnArgs), vp],
     "mvit_layernorm_fwd": [vp, vp, vp, vp, ci, ci, cf, vp],
     "mvit_layernorm_lora_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
+    "mvit_conv3x3_direct_supported": [ci, ci],
+    "mvit_conv3x3_direct": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "mvit_pack_conv3x3_direct": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_lora_pack": [vp, vp, vp, vp, vp, ci, ci, ci, cf, vp],
     "mvit_unpack_conv3x3_wgrad": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp],

@@ -1,0 +1,291 @@
+// Direct 3x3 convolution (stride 1, pad 1) with LDS-staged input tiles for the full-resolution decoder layers with few channels.
+//
+// Reference ops: the conv of Fusion_Block / Basic_Conv3x3 (src/generators/mipheivit.py:20-41,76-93: nn.Conv2d(k=3, s=1, p=1,
+// bias=False) followed by BatchNorm2d) for the last fusion stage (67 -> 32 channels at the tile's full 256 x 256 resolution) and
+// its input gradient (32 -> 64: the adjoint convolution on the flipped, transposed weights).  The implicit-GEMM path re-gathers
+// the 3x3 window of every K tile through L2 (9x the input bytes as L2 -> LDS traffic, 0.2 PFLOP/s on this layer); here a block
+// stages an (8+2) x (32+2) pixel halo tile ONCE in LDS (buffer_load ... lds, zero fill outside the image through out-of-range
+// offsets, double-buffered across the tiles a persistent block walks) and all nine taps read it from there.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16): the product is computed transposed, D[n][pixel] = sum_k W[n][k] X[pixel][k] with
+// A = weight fragment (row = output channel), B = pixel fragment (column = pixel of one 32-pixel row segment), so a lane owns ONE
+// pixel and 4-channel groups of it: the epilogue stores 8-byte pieces straight from the accumulators (no LDS transposition) and
+// BatchNorm statistics are per-lane register sums over all tiles of the block, reduced once at the end.
+// A wave owns two output rows of the tile; per 16-channel K step and horizontal tap kx it reads the four input rows it needs
+// once and uses them for the three vertical taps (12 pixel fragments + 9 weight fragments per 18 MFMAs).
+#include "common.hpp"
+#include "../../include/miphei_hip.h"
+
+namespace {
+
+constexpr int CD_TH = 8, CD_TW = 32;   // output tile: 8 rows x 32 pixels, 4 waves x 2 rows
+
+template <int CIN>
+struct CdGeom {
+  static constexpr int CG = CIN / 8;                                  // 16-byte channel groups per pixel
+  static constexpr int CINK = (CIN + 15) / 16 * 16;                   // K extent per tap (zero padded)
+  static constexpr int WROW = CINK + 8;                               // weight row stride in LDS / global pack (bank spread)
+  static constexpr int UNITS = (CD_TH + 2) * (CD_TW + 2) * CG;        // 16-byte units of one halo tile
+  static constexpr int PIECES = (UNITS + 255) / 256;                  // DMA instructions per wave per tile
+  static constexpr int TILE_BYTES = PIECES * 256 * 16;                // (slack: the last piece may run past the tile)
+  // Bank spread of the pixel fragments: 16 consecutive pixels of a ds_read_b128 lane group must hit 16 distinct 16-byte columns
+  // of the 256-byte bank row.  Column = (CG * pix + slot) mod 16: a permutation for odd CG (72 channels: CG = 9); for CG = 1, 2, 4,
+  // 8 the slot of channel group g is rotated by pix >> SH (the rotation is applied to the SOURCE group of the DMA, the LDS image
+  // itself stays lane-linear).
+  static constexpr bool POW2 = (CG & (CG - 1)) == 0;
+  static constexpr int SH = CG >= 16 ? 0 : (CG == 8 ? 1 : CG == 4 ? 2 : CG == 2 ? 3 : 4);
+  static __device__ __forceinline__ int slot_of(int pix, int g) { return POW2 && CG > 1 ? (g + (pix >> SH)) & (CG - 1) : g; }
+  static __device__ __forceinline__ int group_of(int pix, int slot) { return POW2 && CG > 1 ? (slot - (pix >> SH)) & (CG - 1) : slot; }
+};
+
+template <int CIN, int COUT>
+constexpr size_t cd_lds_bytes() {
+  return (size_t)9 * COUT * CdGeom<CIN>::WROW * 2 + 2 * (size_t)CdGeom<CIN>::TILE_BYTES + 64;
+}
+
+struct CdArgs {
+  const bf16_t* X;       // [B, H, W, ldx] bf16, CIN channels used per pixel
+  const bf16_t* Wp;      // [9][COUT][WROW] packed weights (mvit_pack_conv3x3_direct)
+  bf16_t* Y;             // [B, H, W, ldy] bf16, COUT channels written per pixel
+  double* stats;         // nullable: [nslots][2][COUT] per-channel sum / sum of squares of the f32 results
+  int B, H, W, ldx, ldy, nslots;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(const CdArgs p) {
+  using G = CdGeom<CIN>;
+  constexpr int NT = COUT / 32, NKK = G::CINK / 16;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ws = smem;                                              // [9][COUT][WROW] bf16
+  char* Xs = smem + (size_t)9 * COUT * G::WROW * 2;             // 2 x halo tile
+  char* zero16 = Xs + 2 * (size_t)G::TILE_BYTES;                // 16 zero bytes (+ pad): source of the padded half K step
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // weights: one pass, 16-byte pieces (the pack is already in the LDS image layout)
+  {
+    const int n16 = 9 * COUT * G::WROW / 8;
+    for (int i = tid; i < n16; i += 256) ((uint4*)Ws)[i] = ((const uint4*)p.Wp)[i];
+    if (tid < 4) ((uint4*)zero16)[tid] = make_uint4(0, 0, 0, 0);
+    __syncthreads();      // (no DMA in flight yet: the plain barrier with its waits is what is wanted here)
+  }
+
+  const int tiles_x = (p.W + CD_TW - 1) / CD_TW, tiles_y = (p.H + CD_TH - 1) / CD_TH;
+  const int ntiles = p.B * tiles_y * tiles_x;
+  // whole input as one raw buffer (offsets are bytes; out-of-image pixels use an out-of-range offset -> zeros)
+  const unsigned long long xv = (unsigned long long)p.X;
+  const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xv), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xv >> 32));
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)xhi << 32) | xlo), 0, 0x7fffffff, 0x00020000);
+
+  auto issue_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int y0 = ty * CD_TH - 1, x0 = tx * CD_TW - 1;
+#pragma unroll
+    for (int i = 0; i < G::PIECES; ++i) {
+      const int u = (i * 4 + wave_u) * 64 + lane;              // 16-byte unit of the halo tile image
+      const int pix = u / G::CG, cg = G::group_of(pix, u - pix * G::CG);
+      const int r = pix / (CD_TW + 2), cc = pix - r * (CD_TW + 2);
+      const int iy = y0 + r, ix = x0 + cc;
+      const bool ok = u < G::UNITS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      unsigned off = ok ? (unsigned)((((size_t)b * p.H + iy) * p.W + ix) * p.ldx + cg * 8) * 2u : 0x80000000u;
+      asm volatile("" : "+v"(off));   // one unconditional DMA per piece (the vmcnt accounting counts them)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(Xs + (size_t)buf * G::TILE_BYTES + (size_t)(i * 4 + wave_u) * 1024), 16,
+                                               off, 0, 0, 0);
+    }
+  };
+
+  // per-lane BatchNorm partial sums over every tile of this block: channel n = nt*32 + (r&3) + 8*(r>>2) + 4*half
+  float st_s[NT][16], st_q[NT][16];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st_s[nt][r] = st_q[nt][r] = 0.f;
+
+  int t = blockIdx.x;
+  if (t < ntiles) issue_tile(t, 0);
+  int buf = 0;
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    __builtin_amdgcn_s_barrier();                 // every wave has finished reading the buffer the next tile goes into
+    if (tn < ntiles) {
+      issue_tile(tn, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PIECES) : "memory");   // this tile's pieces have landed, the next tile's fly
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                 // ... and so have the other waves' pieces
+    const char* xs = Xs + (size_t)buf * G::TILE_BYTES;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+
+    // pixel (row ry of the halo tile, column l31 + kx), channels kk*16 + half*8 ..; rows ry = 2*wave .. 2*wave + 3
+    const int rbase = 2 * wave;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const bool kzero = (kk * 16 + half * 8) >= CIN;     // padded half of the last K step: zero pixel fragment (zero weights too)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        bf16x8 xb[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int pix = (rbase + rr) * (CD_TW + 2) + l31 + kx;
+          const char* q = kzero ? zero16 : xs + ((size_t)pix * G::CG + G::slot_of(pix, kk * 2 + half)) * 16;
+          xb[rr] = *(const bf16x8*)q;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 wa = *(const bf16x8*)(Ws + ((size_t)((ky * 3 + kx) * COUT + nt * 32 + l31) * G::WROW + kk * 16 + half * 8) * 2);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[ky], acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[ky + 1], acc[1][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // epilogue: lane = pixel (l31), registers = channel groups of four: 8-byte stores, statistics in registers
+    {
+      const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+      const int ox = tx * CD_TW + l31;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oy = ty * CD_TH + rbase + m;
+        const bool ok = oy < p.H && ox < p.W;
+        bf16_t* yp = p.Y + (((size_t)b * p.H + oy) * p.W + ox) * p.ldy;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float v0 = acc[m][nt][4 * q4], v1 = acc[m][nt][4 * q4 + 1], v2 = acc[m][nt][4 * q4 + 2], v3 = acc[m][nt][4 * q4 + 3];
+            if (ok) {
+              uint2 o;
+              o.x = pack2bf(v0, v1), o.y = pack2bf(v2, v3);
+              *(uint2*)(yp + nt * 32 + 8 * q4 + 4 * half) = o;
+              st_s[nt][4 * q4] += v0, st_s[nt][4 * q4 + 1] += v1, st_s[nt][4 * q4 + 2] += v2, st_s[nt][4 * q4 + 3] += v3;
+              st_q[nt][4 * q4] += v0 * v0, st_q[nt][4 * q4 + 1] += v1 * v1, st_q[nt][4 * q4 + 2] += v2 * v2, st_q[nt][4 * q4 + 3] += v3 * v3;
+            }
+          }
+      }
+    }
+    buf ^= 1;
+  }
+
+  if (p.stats) {
+    // sum over the 32 lanes (pixels) of each half, then over the 4 waves through LDS, then one f64 atomic per channel
+    __builtin_amdgcn_s_barrier();
+    float* red = (float*)Xs;     // [4 waves][2][COUT]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = st_s[nt][r], q = st_q[nt][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          s += __shfl_xor(s, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        if (l31 == 0) {
+          const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          red[(wave * 2 + 0) * COUT + n] = s;
+          red[(wave * 2 + 1) * COUT + n] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < COUT) {
+      double s = 0., q = 0.;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[(w * 2 + 0) * COUT + tid], q += red[(w * 2 + 1) * COUT + tid];
+      double* st = p.stats + (size_t)(blockIdx.x % p.nslots) * 2 * COUT;
+      atomicAdd(st + tid, s);
+      atomicAdd(st + COUT + tid, q);
+    }
+  }
+}
+
+// nn.Conv2d weight [Cout, Cin, 3, 3] f32 -> [9][NOUT][WROW] bf16 for the direct kernel.
+//   mode 0 (forward):  out[tap][n][c]  = W[n][(c + rot) % Cin][ky][kx]                      n < Cout, c < Cin
+//   mode 1 (dgrad):    out[tap][ci][co] = W[co][(ci + rot) % Cin][2 - ky][2 - kx]            ci < NOUT (<= Cin), co < Cout
+// everything else (channel padding, the +8 row pad) is zero.
+__global__ __launch_bounds__(256) void pack_conv_direct_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int Cout,
+                                                               int Cin, int NOUT, int KIN, int WROW, int rot, int mode) {
+  const int total = 9 * NOUT * WROW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int k = i % WROW, n = (i / WROW) % NOUT, tap = i / (WROW * NOUT);
+    const int ky = tap / 3, kx = tap - ky * 3;
+    float v = 0.f;
+    if (k < KIN) {
+      if (mode == 0) {
+        if (n < Cout) v = W[((size_t)n * Cin + (k + rot) % Cin) * 9 + ky * 3 + kx];
+      } else {
+        v = W[((size_t)k * Cin + (n + rot) % Cin) * 9 + (2 - ky) * 3 + (2 - kx)];
+      }
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+template <int CIN, int COUT>
+int launch_direct(const CdArgs& a, hipStream_t s) {
+  const size_t lds = cd_lds_bytes<CIN, COUT>();
+  static mvit_per_device_size raised;
+  auto kern = conv3x3_direct_kernel<CIN, COUT>;
+  if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return MVIT_EINVAL;
+  const int tiles = a.B * ((a.H + CD_TH - 1) / CD_TH) * ((a.W + CD_TW - 1) / CD_TW);
+  const int blocks = tiles < mvit_num_cus() ? tiles : mvit_num_cus();      // one persistent block per CU (LDS)
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+  return MVIT_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" {
+
+MVIT_API int mvit_conv3x3_direct_supported(int Cin_pad, int Cout) {
+  return (Cout == 32 && (Cin_pad == 72 || Cin_pad == 64 || Cin_pad == 32 || Cin_pad == 8)) || (Cout == 64 && Cin_pad == 32);
+}
+
+MVIT_API int mvit_conv3x3_direct(const void* X, const void* Wp, void* Y, double* stats, int nslots, int B, int H, int W, int Cin_pad,
+                                 int ldx, int Cout, int ldy, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0 || (ldx & 7) || ldx < Cin_pad || (ldy & 3) || ldy < Cout || (stats && nslots <= 0))
+    return MVIT_EINVAL;
+  if ((size_t)B * H * W * ldx * 2 >= 0x7fffffffull) return MVIT_EINVAL;   // 32-bit byte offsets of the raw buffer
+  CdArgs a{(const bf16_t*)X, (const bf16_t*)Wp, (bf16_t*)Y, stats, B, H, W, ldx, ldy, nslots};
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout == 32) {
+    if (Cin_pad == 72) return launch_direct<72, 32>(a, s);
+    if (Cin_pad == 64) return launch_direct<64, 32>(a, s);
+    if (Cin_pad == 32) return launch_direct<32, 32>(a, s);
+    if (Cin_pad == 8) return launch_direct<8, 32>(a, s);
+  } else if (Cout == 64) {
+    if (Cin_pad == 32) return launch_direct<32, 64>(a, s);
+  }
+  return MVIT_EINVAL;
+}
+
+MVIT_API int mvit_pack_conv3x3_direct(const float* W, void* out, int Cout, int Cin, int n_out, int k_in, int k_pad, int rot,
+                                      int mode, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!W || !out || Cout <= 0 || Cin <= 0 || n_out <= 0 || k_in <= 0 || k_pad < k_in || (k_pad & 7) || rot < 0 ||
+      (mode != 0 && mode != 1))
+    return MVIT_EINVAL;
+  if (mode == 0 && (k_in > Cin || n_out < Cout)) return MVIT_EINVAL;
+  if (mode == 1 && (k_in > Cout || n_out > Cin)) return MVIT_EINVAL;
+  const int wrow = (k_pad + 15) / 16 * 16 + 8;
+  const int total = 9 * n_out * wrow;
+  hipLaunchKernelGGL(pack_conv_direct_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, W, (bf16_t*)out, Cout, Cin, n_out, k_in, wrow, rot, mode);
+  return MVIT_LAUNCH_CHECK();
+}
+
+}  // extern "C"

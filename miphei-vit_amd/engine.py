@@ -314,6 +314,7 @@ class HipEngine:
             return pk
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
+        pk.wdir_f = pk.wdir_b = None
         for i, cv in enumerate(convs):
             w = f32(cv.conv.weight).contiguous()                                    # [Cout, Cin, 3, 3]
             cout, cin = w.shape[0], w.shape[1]
@@ -326,6 +327,12 @@ class HipEngine:
             pk.wk.append(wk)
             if need_bwd:
                 pk.wd.append(wd)
+            if last and ops.conv3x3_direct_supported(cp, cout):
+                # last fusion block (67 -> 32 at full resolution): direct convolution with LDS-staged halo tiles, forward and
+                # (64 up-sampled channels only) input gradient
+                pk.wdir_f = ops.pack_conv3x3_direct(w, cout, cp, rot=3)
+                if need_bwd and ops.conv3x3_direct_supported(_pad8(cout), FUS_OUT[2]):
+                    pk.wdir_b = ops.pack_conv3x3_direct(w, FUS_OUT[2], _pad8(cout), rot=3, dgrad=True)
             pk.cin.append(cin)
             pk.cin_pad.append(cp)
             pk.perm.append(perm)
@@ -564,7 +571,10 @@ class HipEngine:
             cat = w.cat[j]
             cp = cat.shape[-1]
             i = 3 + j
-            if bn_train:
+            if j == 3 and pk.wdir_f is not None and cat.numel() * 2 < 2 ** 31:    # (32-bit byte offsets of its raw buffer)
+                ops.conv3x3_direct(cat, pk.wdir_f, w.pre_f[j], B=B, H=r, W=r, cin_pad=cp, ldx=cp, cout=FUS_OUT[j], ldy=FUS_OUT[j],
+                                   stats=w.stats_f[i] if bn_train else None, nslots=NSLOTS)
+            elif bn_train:
                 ops.gemm(cat, pk.wk[i], w.pre_f[j], M=Mo, amode=A_CONV3, conv=(r, r, cp, cp, r, r, 1), epi=EPI_STATS,
                          stats=w.stats_f[i], nslots=NSLOTS)
             else:
@@ -699,8 +709,12 @@ class HipEngine:
             # dgrad into the concat-gradient buffer (fus3: only the 64 upsampled channels carry gradient)
             ncols = FUS_OUT[2] if j == 3 else cp
             dcat = w.dcat[j]
-            ops.gemm(w.dpre_f[j], pk.wd[i], dcat, M=Mo, N=ncols, amode=A_CONV3_T, conv=(r, r, cout, cout, r, r, 1),
-                     ldc=dcat.shape[-1])
+            if j == 3 and pk.wdir_b is not None and w.dpre_f[j].numel() * 2 < 2 ** 31:
+                ops.conv3x3_direct(w.dpre_f[j], pk.wdir_b, dcat, B=B, H=r, W=r, cin_pad=cout, ldx=cout, cout=ncols,
+                                   ldy=dcat.shape[-1])
+            else:
+                ops.gemm(w.dpre_f[j], pk.wd[i], dcat, M=Mo, N=ncols, amode=A_CONV3_T, conv=(r, r, cout, cout, r, r, 1),
+                         ldc=dcat.shape[-1])
             if j > 0:
                 # adjoint of the bilinear x2 upsample -> gradient w.r.t. relu(BN(pre_f[j-1]))
                 off = 0 if j == 3 else CONV_CH[3 - j]

@@ -268,6 +268,34 @@ def pack_conv3x3_weights(W, wk, wd, rot=0):
     _call("mvit_pack_conv3x3_weights", _p(W), _p(wk), _p(wd), cout, cin, cp, rot)
 
 
+def conv3x3_direct_supported(cin_pad, cout):
+    return bool(L.lib().mvit_conv3x3_direct_supported(cin_pad, cout))
+
+
+def pack_conv3x3_direct(W, n_out, k_pad, rot=0, dgrad=False):
+    """nn.Conv2d weight [Cout,Cin,3,3] f32 -> operand of mvit_conv3x3_direct: [9, n_out, ceil16(k_pad)+8] bf16.
+    dgrad=False: forward (k = input channel, rot as pack_conv3x3_weights); dgrad=True: adjoint (k = output channel of the
+    forward conv, n = its input channels (n + rot) % Cin, taps flipped)."""
+    assert W.dtype == torch.float32 and W.is_contiguous()
+    cout, cin = W.shape[0], W.shape[1]
+    k_in = cout if dgrad else cin
+    wrow = (k_pad + 15) // 16 * 16 + 8
+    out = torch.empty(9, n_out, wrow, device=W.device, dtype=torch.bfloat16)
+    _call("mvit_pack_conv3x3_direct", _p(W), _p(out), cout, cin, n_out, k_in, k_pad, rot, int(dgrad))
+    return out
+
+
+def conv3x3_direct(x, wp, y, *, B, H, W, cin_pad, ldx, cout, ldy, stats=None, nslots=0):
+    """y[b,h,w,:cout] = conv3x3(x[b,h,w,:cin_pad]) (stride 1, pad 1, NHWC bf16) with LDS-staged input tiles"""
+    _chk_bf16(x, "x")
+    _chk_bf16(wp, "wp")
+    _chk_bf16(y, "y")
+    if stats is not None:
+        assert stats.dtype == torch.float64
+    _call("mvit_conv3x3_direct", _p(x), _p(wp), _p(y), _p(stats), nslots, B, H, W, cin_pad, ldx, cout, ldy)
+    return y
+
+
 def pixel_shuffle2x(packed, img, B, H, W, C_, ld_img, inverse=False):
     _call("mvit_pixel_shuffle2x", _p(packed), _p(img), B, H, W, C_, ld_img, int(inverse))
 
