@@ -236,6 +236,12 @@ MVIT_API int mvit_pix_metrics_update(const float* pred, const float* target, dou
 MVIT_API int mvit_conv3x3_direct_supported(int Cin_pad, int Cout);
 MVIT_API int mvit_conv3x3_direct(const void* X, const void* Wp, void* Y, double* stats, int nslots, int B, int H, int W, int Cin_pad,
                                  int ldx, int Cout, int ldy, mvit_stream_t stream);
+/* Weight gradient of the same convolution, dWn[n][(ky,kx,c)] (f32, [Cout][9*Cin_pad], accumulated into with atomics; unpack with
+ * mvit_unpack_conv3x3_wgrad(n_major = 1)) = sum over pixels of X[pixel+(ky-1,kx-1)][c] * dY[pixel][n]: the parameter side of
+ * loss.backward() for the last Fusion_Block conv (src/models.py:135).  X halo tiles and dY tiles are staged in LDS once; the
+ * contraction over pixels uses transposing LDS reads.  (Cin_pad, Cout) in {(72,32), (32,32), (8,32)}. */
+MVIT_API int mvit_conv3x3_direct_wgrad(const void* X, const void* dY, float* dWn, int B, int H, int W, int Cin_pad, int ldx,
+                                       int Cout, int ldy, mvit_stream_t stream);
 /* nn.Conv2d weight [Cout,Cin,3,3] f32 -> Wp [9][n_out][ceil16(k_pad) + 8] bf16 (zero padded).
  * mode 0 (forward, k_in = Cin, n_out >= Cout):  Wp[tap][n][c]   = W[n][(c+rot) % Cin][ky][kx]
  * mode 1 (input gradient, k_in = Cout, n_out <= Cin input channels wanted):  Wp[tap][ci][co] = W[co][(ci+rot) % Cin][2-ky][2-kx] */
@@ -248,10 +254,11 @@ MVIT_API int mvit_pack_conv3x3_direct(const float* W, void* out, int Cout, int C
  * rows / v rows, zero elsewhere: the K-extension of the qkv GEMM), Bqv [L,2,r,D] = alpha*Bq, alpha*Bv (may be NULL). */
 MVIT_API int mvit_lora_pack(const float* lora, void* AcatT, void* Acat, void* B2, void* Bqv, int L, int D, int r, float alpha,
                             mvit_stream_t stream);
-/* Weight gradient of a 3x3 convolution from the TN-GEMM layout dWt [(ky,kx,c_pad), Cout] f32 to nn.Conv2d's [Cout,Cin,3,3]
- * (inverse of mvit_pack_conv3x3_weights incl. its channel rotation); accumulate != 0 adds to dW. */
+/* Weight gradient of a 3x3 convolution from the TN-GEMM layout dWt [(ky,kx,c_pad), Cout] f32 (n_major != 0: from the direct
+ * kernel's [Cout, (ky,kx,c_pad)]) to nn.Conv2d's [Cout,Cin,3,3] (inverse of mvit_pack_conv3x3_weights incl. its channel
+ * rotation); accumulate != 0 adds to dW. */
 MVIT_API int mvit_unpack_conv3x3_wgrad(const float* dWt, float* dW, int Cout, int Cin, int Cp, int rot, int accumulate,
-                                       mvit_stream_t stream);
+                                       int n_major, mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- loss / optimiser */
 /* WeightedMSELoss (src/loss.py:47-57): loss_acc += sum_c w_c sum (p-t)^2 (caller multiplies by lambda/(C*B*HW));

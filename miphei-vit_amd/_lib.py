@@ -50,7 +50,8 @@ SIGNATURES = {
     "mvit_conv3x3_direct": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_pack_conv3x3_direct": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_lora_pack": [vp, vp, vp, vp, vp, ci, ci, ci, cf, vp],
-    "mvit_unpack_conv3x3_wgrad": [vp, vp, ci, ci, ci, ci, ci, vp],
+    "mvit_unpack_conv3x3_wgrad": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "mvit_conv3x3_direct_wgrad": [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp],
     "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
     "mvit_skinny_xw2": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],

@@ -212,6 +212,172 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const CdArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ weight gradient
+// dWn[n][(ky,kx,c)] += sum_pixels X[pixel + (ky-1, kx-1)][c] * dY[pixel][n]   (f32 atomics; output-channel major, so that the
+// lanes of a wave -- consecutive c -- add to consecutive addresses).
+// Same staging as the forward kernel (halo tile of X plus the 8 x 32 tile of dY, both DMA'd and double-buffered); the contraction
+// runs over PIXELS, so both MFMA operands are gathered with the transposing LDS read (ds_read_b64_tr_b16: 4 consecutive pixels of
+// one channel per lane).  D[n][c] tiles: 9 taps x ceil(CIN / 32) channel tiles, dealt round-robin to the 4 waves, which keep them
+// in registers over every tile of the persistent block (the dY fragments of a tile, 16 K steps, are read once per wave and held
+// in registers); one pass of atomics per block at the end.
+typedef short v4s_cd __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 cd_join(v4s_cd a, v4s_cd b) {
+  union { struct { v4s_cd lo, hi; } s; bf16x8 v; } u;
+  u.s.lo = a;
+  u.s.hi = b;
+  return u.v;
+}
+// 4 consecutive rows (stride `rs` bytes) x this lane's column: lane i of a 16-lane group addresses row i>>2, columns 4*(i&3)..+3
+// and receives column i of the 4 x 16 block
+__device__ __forceinline__ v4s_cd cd_tr4(const char* base, int rs, int col16, int lane) {
+  const int i = lane & 15;
+  const char* q = base + (i >> 2) * rs + (col16 + 4 * (i & 3)) * 2;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_cd*)q);
+}
+
+template <int CIN, int COUT>
+struct CwGeom {
+  static constexpr int CT = (CIN + 31) / 32;                 // 32-channel tiles of the input channels
+  static constexpr int NPAIR = 9 * CT;                       // (tap, channel tile) accumulators in total
+  static constexpr int PER_WAVE = (NPAIR + 3) / 4;
+  static constexpr int DY_BYTES = CD_TH * CD_TW * COUT * 2;  // dY tile
+  static constexpr int DY_PIECES = DY_BYTES / (256 * 16);
+  static_assert(DY_BYTES % (256 * 16) == 0, "dY tile must be whole DMA rounds");
+};
+
+template <int CIN, int COUT>
+constexpr size_t cw_lds_bytes() {
+  return 2 * (size_t)CdGeom<CIN>::TILE_BYTES + 2 * (size_t)CwGeom<CIN, COUT>::DY_BYTES + 512;
+}
+
+struct CwArgs {
+  const bf16_t* X;     // [B, H, W, ldx]
+  const bf16_t* dY;    // [B, H, W, ldy], COUT channels
+  float* dWt;          // [COUT][9 * CIN] f32 (output-channel major, k = tap * CIN + c), accumulated into
+  int B, H, W, ldx, ldy;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const CwArgs p) {
+  static_assert(COUT == 32, "one 32-row MFMA tile of output channels");
+  using G = CdGeom<CIN>;
+  using Wg = CwGeom<CIN, COUT>;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;                                     // 2 x halo tile of X (pixel-major, CIN channels, no channel rotation here)
+  char* Ys = smem + 2 * (size_t)G::TILE_BYTES;         // 2 x dY tile [256 pixels][COUT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int l31 = lane & 31, half = lane >> 5, sub = (lane >> 4) & 1;
+  const int tiles_x = (p.W + CD_TW - 1) / CD_TW, tiles_y = (p.H + CD_TH - 1) / CD_TH;
+  const int ntiles = p.B * tiles_y * tiles_x;
+  auto rsrc = [](const void* ptr) __attribute__((always_inline)) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsX = rsrc(p.X), rsY = rsrc(p.dY);
+
+  auto issue_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int y0 = ty * CD_TH - 1, x0 = tx * CD_TW - 1;
+#pragma unroll
+    for (int i = 0; i < G::PIECES; ++i) {
+      const int u = (i * 4 + wave_u) * 64 + lane;
+      const int pix = u / G::CG, cg = u - pix * G::CG;
+      const int r = pix / (CD_TW + 2), cc = pix - r * (CD_TW + 2);
+      const int iy = y0 + r, ix = x0 + cc;
+      const bool ok = u < G::UNITS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      unsigned off = ok ? (unsigned)((((size_t)b * p.H + iy) * p.W + ix) * p.ldx + cg * 8) * 2u : 0x80000000u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(Xs + (size_t)buf * G::TILE_BYTES + (size_t)(i * 4 + wave_u) * 1024), 16,
+                                               off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < Wg::DY_PIECES; ++i) {
+      const int u = (i * 4 + wave_u) * 64 + lane;     // 16-byte unit of the dY tile: pixel u / (COUT/8), group u % (COUT/8)
+      const int pix = u / (COUT / 8), cg = u - pix * (COUT / 8);
+      const int oy = ty * CD_TH + pix / CD_TW, ox = tx * CD_TW + pix % CD_TW;
+      const bool ok = oy < p.H && ox < p.W;             // pixels outside the image contribute zero gradient
+      unsigned off = ok ? (unsigned)((((size_t)b * p.H + oy) * p.W + ox) * p.ldy + cg * 8) * 2u : 0x80000000u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_ptr)(Ys + (size_t)buf * Wg::DY_BYTES + (size_t)(i * 4 + wave_u) * 1024), 16,
+                                               off, 0, 0, 0);
+    }
+  };
+  constexpr int NDMA = G::PIECES + Wg::DY_PIECES;
+
+  f32x16 acc[Wg::PER_WAVE];
+#pragma unroll
+  for (int a = 0; a < Wg::PER_WAVE; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  int t = blockIdx.x;
+  if (t < ntiles) issue_tile(t, 0);
+  int buf = 0;
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    __builtin_amdgcn_s_barrier();
+    if (tn < ntiles) {
+      issue_tile(tn, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* xs = Xs + (size_t)buf * G::TILE_BYTES;
+    const char* ys = Ys + (size_t)buf * Wg::DY_BYTES;
+    // A operand (rows = output channels n, K = pixels): the 16 K steps of the tile, held in registers for all pairs of this wave.
+    // K step s = pixels [16 s, 16 s + 16) of the tile (row s >> 1, columns 16 (s & 1) ..); K-slot order of the fragments:
+    // half 0 -> pixels {0-3, 8-11}, half 1 -> {4-7, 12-15} of the step (the same order is used for the B operand).
+    bf16x8 fa[16];
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      const char* base = ys + (size_t)(16 * s_ + 4 * half) * (COUT * 2);
+      fa[s_] = cd_join(cd_tr4(base, COUT * 2, 16 * sub, lane), cd_tr4(base + 8 * COUT * 2, COUT * 2, 16 * sub, lane));
+    }
+#pragma unroll
+    for (int a = 0; a < Wg::PER_WAVE; ++a) {
+      const int pair = a * 4 + wave;                   // (tap, channel tile) of this accumulator
+      if (pair < Wg::NPAIR) {
+        const int tap = pair / Wg::CT, ct = pair - tap * Wg::CT;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int cb = ct * 32 + 16 * sub;             // this lane group's 16 channels
+        const bool cok = cb < CIN;                     // (CIN % 16 == 8: the last 16-channel group is half padding, handled below)
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+          const int prow = (s_ >> 1) + ky, pcol = 16 * (s_ & 1) + kx + 4 * half;
+          const char* base = xs + ((size_t)(prow * (CD_TW + 2) + pcol) * CIN) * 2;
+          bf16x8 fb;
+          if (cok) {
+            fb = cd_join(cd_tr4(base, CIN * 2, cb, lane), cd_tr4(base + 8 * CIN * 2, CIN * 2, cb, lane));
+          } else {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            fb = *(const bf16x8*)&z;
+          }
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_], fb, acc[a], 0, 0, 0);
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  // D[n][c]: column c = lane & 31 of the channel tile, row n = (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int a = 0; a < Wg::PER_WAVE; ++a) {
+    const int pair = a * 4 + wave;
+    if (pair >= Wg::NPAIR) continue;
+    const int tap = pair / Wg::CT, ct = pair - tap * Wg::CT;
+    const int c = ct * 32 + l31;
+    if (c >= CIN) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
+      atomicAdd(p.dWt + (size_t)n * (9 * CIN) + tap * CIN + c, acc[a][r]);   // lanes -> consecutive c: one line per half wave
+    }
+  }
+}
+
 // nn.Conv2d weight [Cout, Cin, 3, 3] f32 -> [9][NOUT][WROW] bf16 for the direct kernel.
 //   mode 0 (forward):  out[tap][n][c]  = W[n][(c + rot) % Cin][ky][kx]                      n < Cout, c < Cin
 //   mode 1 (dgrad):    out[tap][ci][co] = W[co][(ci + rot) % Cin][2 - ky][2 - kx]            ci < NOUT (<= Cin), co < Cout
@@ -246,9 +412,33 @@ int launch_direct(const CdArgs& a, hipStream_t s) {
   return MVIT_LAUNCH_CHECK();
 }
 
+template <int CIN, int COUT>
+int launch_direct_wgrad(const CwArgs& a, hipStream_t s) {
+  const size_t lds = cw_lds_bytes<CIN, COUT>();
+  static mvit_per_device_size raised;
+  auto kern = conv3x3_direct_wgrad_kernel<CIN, COUT>;
+  if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return MVIT_EINVAL;
+  const int tiles = a.B * ((a.H + CD_TH - 1) / CD_TH) * ((a.W + CD_TW - 1) / CD_TW);
+  const int blocks = tiles < mvit_num_cus() ? tiles : mvit_num_cus();
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+  return MVIT_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 extern "C" {
+
+MVIT_API int mvit_conv3x3_direct_wgrad(const void* X, const void* dY, float* dWt, int B, int H, int W, int Cin_pad, int ldx, int Cout,
+                                       int ldy, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!X || !dY || !dWt || B <= 0 || H <= 0 || W <= 0 || (ldx & 7) || ldx < Cin_pad || (ldy & 7) || ldy < Cout) return MVIT_EINVAL;
+  if ((size_t)B * H * W * ldx * 2 >= 0x7fffffffull || (size_t)B * H * W * ldy * 2 >= 0x7fffffffull) return MVIT_EINVAL;
+  CwArgs a{(const bf16_t*)X, (const bf16_t*)dY, dWt, B, H, W, ldx, ldy};
+  if (Cout == 32 && Cin_pad == 72) return launch_direct_wgrad<72, 32>(a, (hipStream_t)stream);
+  if (Cout == 32 && Cin_pad == 32) return launch_direct_wgrad<32, 32>(a, (hipStream_t)stream);
+  if (Cout == 32 && Cin_pad == 8) return launch_direct_wgrad<8, 32>(a, (hipStream_t)stream);
+  return MVIT_EINVAL;
+}
 
 MVIT_API int mvit_conv3x3_direct_supported(int Cin_pad, int Cout) {
   return (Cout == 32 && (Cin_pad == 72 || Cin_pad == 64 || Cin_pad == 32 || Cin_pad == 8)) || (Cout == 64 && Cin_pad == 32);

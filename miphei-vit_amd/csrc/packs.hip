@@ -45,15 +45,16 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
   }
 }
 
-// dWt [(ky,kx,c_pad), Cout] f32 (output of the TN weight-gradient GEMM) -> parameter layout dW [Cout, Cin, 3, 3];
+// dWt [(ky,kx,c_pad), Cout] f32 (output of the TN weight-gradient GEMM; n_major: [Cout, (ky,kx,c_pad)], the direct kernel's)
+// -> parameter layout dW [Cout, Cin, 3, 3];
 // packed channel c is parameter channel (c + rot) mod Cin (see pack_conv_w_kernel); the Cp - Cin pad rows are dropped.
 __global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const float* __restrict__ dWt, float* __restrict__ dW, int Cout,
-                                                                int Cin, int Cp, int rot, int accumulate) {
+                                                                int Cin, int Cp, int rot, int accumulate, int n_major) {
   const int total = Cout * Cin * 9;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int t = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
     const int c = (ci - rot % Cin + Cin) % Cin;
-    const float v = dWt[((size_t)t * Cp + c) * Cout + co];
+    const float v = n_major ? dWt[(size_t)co * 9 * Cp + (size_t)t * Cp + c] : dWt[((size_t)t * Cp + c) * Cout + co];
     dW[i] = accumulate ? dW[i] + v : v;
   }
 }
@@ -73,12 +74,12 @@ MVIT_API int mvit_lora_pack(const float* lora, void* AcatT, void* Acat, void* B2
 }
 
 MVIT_API int mvit_unpack_conv3x3_wgrad(const float* dWt, float* dW, int Cout, int Cin, int Cp, int rot, int accumulate,
-                                       mvit_stream_t stream) {
+                                       int n_major, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (!dWt || !dW || Cout <= 0 || Cin <= 0 || Cp < Cin || rot < 0) return MVIT_EINVAL;
   const int total = Cout * Cin * 9;
   hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, dWt, dW, Cout, Cin, Cp, rot, accumulate);
+                     (hipStream_t)stream, dWt, dW, Cout, Cin, Cp, rot, accumulate, n_major);
   return MVIT_LAUNCH_CHECK();
 }
 

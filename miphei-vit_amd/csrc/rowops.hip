@@ -52,133 +52,102 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------ LayerNorm forward + LoRA down-projection
-// h = LN(x) (bf16) and, from the row while it is still in registers, t = h @ [A_q | A_v]  ([M, R2], R2 = 2*rank <= 16):
-// the LoRA products of QkvWithLoRA (src/generators/lora.py:16-18,29-33) start from the same LN1 output the qkv GEMM reads, so
-// the separate skinny GEMM (one more pass over h, one more launch per block) disappears.  The adapter matrix is staged in
-// LDS as AcatT [R2, D] bf16 (48 KB for D = 1536); each lane multiplies its 4-element groups of the bf16-rounded row with
-// v_dot2c_f32_bf16 (same products as the bf16 MFMA path: bf16 x bf16, f32 accumulate) and the R2 partial sums are
-// reduced across the wave with a halving butterfly (R2/2 + R2/4 + ... exchanges instead of 6 per value).
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_v;
-constexpr int LNL_WAVES = 8;   // waves per block sharing one LDS image of the adapters; two blocks per CU (<= 128 VGPRs)
+// h = LN(x) (bf16) and t = h @ [A_q | A_v]  ([M, R2], R2 = 2*rank <= 16) in one launch: the LoRA products of QkvWithLoRA
+// (src/generators/lora.py:16-18,29-33) start from the same LN1 output the qkv GEMM reads, so the separate skinny GEMM (one more
+// pass over h, one more launch per block) disappears.
+// A block normalises 16 rows, one per wave (row in registers, wave-level statistics, as ln_fwd_kernel), and parks the bf16 rows
+// in LDS next to the adapter matrix AcatT [R2, D]; after one barrier four of its waves run the 16-row x 16-column product on
+// v_mfma_f32_16x16x32_bf16 -- A fragments (row = token) and B fragments (column = adapter column) are plain 16-byte LDS reads,
+// the 32-wide K steps are dealt to the four waves and their partial blocks summed through LDS.  Row images are padded by 16 bytes
+// so that the 16 rows of a fragment read fall on distinct banks.
+#ifndef MVIT_LNL_ROWS
+#define MVIT_LNL_ROWS 16
+#endif
+constexpr int LNL_ROWS = MVIT_LNL_ROWS;   // rows (= waves) per block: 16, or 8 with the upper half of the MFMA rows idle
 template <int NV>  // float4 groups per lane: D <= 256 * NV
-__global__ __launch_bounds__(64 * LNL_WAVES, 4) void ln_fwd_lora_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ b, bf16_t* __restrict__ out,
-                                                          const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t, int M, int D,
-                                                          float eps, int R2) {
+__global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, bf16_t* __restrict__ out,
+                                                                    const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t,
+                                                                    int M, int D, float eps, int R2) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  uint2* As = (uint2*)lds_raw;                       // [R2][D/4] groups of 4 bf16
+  const int RS = D * 2 + 16;                          // padded row image (bytes)
+  char* As = lds_raw;                                 // [16][RS]: AcatT rows (rows >= R2 zero)
+  char* Hs = lds_raw + 16 * RS;                       // [LNL_ROWS][RS]: the block's normalised rows
+  float* part = (float*)(Hs + LNL_ROWS * RS);         // [3][64][4] partial blocks of waves 1..3
   const int nv = D >> 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * LNL_WAVES + wave;
-  // Persistent blocks, a wave walks rows row0, row0 + (waves in the grid), ...: the adapter image (L2-resident, 16-byte pieces) is
-  // staged once per block, and the NEXT row's loads are issued before the current row is reduced, so a second trip costs its
-  // arithmetic, not another HBM round trip.
-  const int stride = gridDim.x * LNL_WAVES;
-  float4 vn[NV];
-  auto load_row = [&](int r) __attribute__((always_inline)) {
-    const float4* xr = (const float4*)(x + (size_t)(r < M ? r : M - 1) * D) + lane;   // + 64 * i: immediate offsets
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < nv) vn[i] = xr[64 * i];
-    }
-  };
-  load_row(row0);
+  const int row = blockIdx.x * LNL_ROWS + wave;
+  float4 v[NV];
   {
-    // LDS image [R2][NV * 64] groups (row stride fixed at compile time: every ds_read of the dot phase is base + immediate)
-    const int h = nv >> 1;                           // 16-byte pieces per adapter row (D % 8 == 0 is checked by the host)
-    for (int i = threadIdx.x; i < R2 * h; i += 64 * LNL_WAVES) {
-      const int j = i / h, c = i - j * h;
-      ((uint4*)lds_raw)[j * (NV * 32) + c] = ((const uint4*)AcatT)[i];
+    const float4* xr = (const float4*)(x + (size_t)(row < M ? row : M - 1) * D) + lane;   // + 64 * i: immediate offsets
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nv) v[i] = xr[64 * i];
+  }
+  {
+    const int h16 = D >> 3;                           // 16-byte pieces per adapter row (D % 8 == 0 is checked by the host)
+    for (int i = threadIdx.x; i < 16 * h16; i += 64 * LNL_ROWS) {
+      const int j = i / h16, c = i - j * h16;
+      *(uint4*)(As + j * RS + c * 16) = j < R2 ? ((const uint4*)AcatT)[(size_t)j * h16 + c] : make_uint4(0, 0, 0, 0);
     }
   }
-  __syncthreads();
-  for (int row = row0; row < M; row += stride) {
-    float4 v[NV];
+  float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = vn[i];
-    if (row + stride < M) load_row(row + stride);
-    float s = 0.f;
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nv) {
+      const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + bb * bb) + (c * c + d * d);
     }
-    const float mu = wave_sum(s) / D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < nv) {
-        const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-        q += (a * a + bb * bb) + (c * c + d * d);
-      }
-    }
-    const float rs = rsqrtf(wave_sum(q) / D + eps);
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  {
     uint2* o = (uint2*)(out + (size_t)row * D) + lane;
+    uint2* hl = (uint2*)(Hs + wave * RS) + lane;
     const float4* wl = (const float4*)w + lane;
     const float4* bl = (const float4*)b + lane;
-    uint2 rp[NV];                                    // the normalised row as packed bf16 (what the qkv GEMM will read)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < nv) {
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nv) {
         const float4 ww = wl[64 * i], bv = bl[64 * i];
-        rp[i].x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
-        rp[i].y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
-        o[64 * i] = rp[i];
+        uint2 r;
+        r.x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
+        r.y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
+        if (row < M) o[64 * i] = r;
+        hl[64 * i] = r;
       }
-      // (the scale / shift vectors of at most two groups in flight: hoisting all NV pairs costs 8 registers each)
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);               // the f32 row is dead from here on: keep the dot phase out of its live range
-    float acc[16];
+  }
+  __syncthreads();
+  if (wave >= 4) return;
+  // t block [16 tokens][16 columns]: K steps of 32, step ks handled by wave ks % 4
+  const int r16 = lane & 15, kq = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const char* ha = Hs + (r16 & (LNL_ROWS - 1)) * RS + kq * 16;   // (rows beyond LNL_ROWS repeat: their results are not stored)
+  const char* ab = As + r16 * RS + kq * 16;
+  const int nks = D >> 5;
+  for (int ks = wave; ks < nks; ks += 4) {
+    const bf16x8 fa = *(const bf16x8*)(ha + ks * 64);
+    const bf16x8 fb = *(const bf16x8*)(ab + ks * 64);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+  }
+  if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      __builtin_amdgcn_sched_barrier(0);
-      if (idx < nv) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j < R2) {
-            const uint2 a = As[j * (NV * 64) + idx];
-            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&rp[i].x, *(const bf16x2_v*)&a.x, acc[j], false);
-            acc[j] = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2_v*)&rp[i].y, *(const bf16x2_v*)&a.y, acc[j], false);
-          }
-        }
-      }
-    }
-    // halving butterfly: after the exchange with lane^32 the lower half owns values 0..7 and the upper half 8..15, and so on;
-    // lane L ends up with value index (L >> 2) & 15 summed over its 4-lane group's partners, two more steps finish it
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool up = lane & 32;
-      const float send = up ? acc[j] : acc[j + 8], keep = up ? acc[j + 8] : acc[j];
-      acc[j] = keep + __shfl_xor(send, 32, 64);
-    }
+    for (int j = 0; j < 4; ++j) part[((wave - 1) * 64 + lane) * 4 + j] = acc[j];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the partial blocks are in LDS
+  __builtin_amdgcn_s_barrier();         // (waves 4..15 have left: the barrier counts the four that remain)
+  // C/D layout of the 16x16 MFMA: col = lane & 15 (adapter column), row = (lane >> 4) * 4 + reg (token)
+  if (wave == 0 && r16 < R2) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool up = lane & 16;
-      const float send = up ? acc[j] : acc[j + 4], keep = up ? acc[j + 4] : acc[j];
-      acc[j] = keep + __shfl_xor(send, 16, 64);
+      const int orow = blockIdx.x * LNL_ROWS + kq * 4 + j;
+      if (kq * 4 + j >= LNL_ROWS) continue;
+      const float val = acc[j] + part[(0 * 64 + lane) * 4 + j] + part[(1 * 64 + lane) * 4 + j] + part[(2 * 64 + lane) * 4 + j];
+      if (orow < M) t[(size_t)orow * R2 + r16] = f2bf(val);
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool up = lane & 8;
-      const float send = up ? acc[j] : acc[j + 2], keep = up ? acc[j + 2] : acc[j];
-      acc[j] = keep + __shfl_xor(send, 8, 64);
-    }
-    {
-      const bool up = lane & 4;
-      const float send = up ? acc[0] : acc[1], keep = up ? acc[1] : acc[0];
-      acc[0] = keep + __shfl_xor(send, 4, 64);
-    }
-    acc[0] += __shfl_xor(acc[0], 2, 64);
-    acc[0] += __shfl_xor(acc[0], 1, 64);
-    const int j = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    if ((lane & 3) == 0 && j < R2) t[(size_t)row * R2 + j] = f2bf(acc[0]);
   }
 }
 
@@ -397,12 +366,11 @@ MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, 
 MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float* b, void* out, const void* AcatT, void* t,
                                      int M, int D, float eps, int R2, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (M <= 0 || D <= 0 || (D & 7) || D > 256 * LN_MAXV || R2 <= 0 || R2 > 16 || !AcatT || !t) return MVIT_EINVAL;
-  const size_t lds = (size_t)R2 * ((D + 511) / 512 * 512) * 2;   // rows padded to the kernel's compile-time stride
+  if (M <= 0 || D <= 0 || (D & 31) || D > 256 * LN_MAXV || R2 <= 0 || R2 > 16 || !AcatT || !t) return MVIT_EINVAL;
+  const size_t lds = (16 + LNL_ROWS) * ((size_t)D * 2 + 16) + 3 * 64 * 4 * sizeof(float);
   auto launch = [&](auto kern, mvit_per_device_size& raised) {
     if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return (int)MVIT_EINVAL;
-    const int want = (M + LNL_WAVES - 1) / LNL_WAVES, cap = 2 * mvit_num_cus();   // two resident blocks per CU
-    hipLaunchKernelGGL(kern, dim3(want < cap ? want : cap), dim3(64 * LNL_WAVES), lds, (hipStream_t)stream, x, w, b,
+    hipLaunchKernelGGL(kern, dim3((M + LNL_ROWS - 1) / LNL_ROWS), dim3(64 * LNL_ROWS), lds, (hipStream_t)stream, x, w, b,
                        (bf16_t*)out, (const bf16_t*)AcatT, (bf16_t*)t, M, D, eps, R2);
     return MVIT_LAUNCH_CHECK();
   };

@@ -705,7 +705,14 @@ class HipEngine:
             bn = convs[i].bn
             ops.bn_relu_bwd(dy_post, ld_post, w.pre_f[j], bp.scale, bp.shift, bp.mean, bp.rstd, pk.bn[i].w, w.stats_b[i],
                             fl.gview[id(bn.weight)], fl.gview[id(bn.bias)], w.dpre_f[j], Mo, cout, NSLOTS)
-            self._wgrad(w, i, cat, r, cp, cp, r, 1, w.dpre_f[j], cout)
+            if j == 3 and pk.wdir_f is not None and cat.numel() * 2 < 2 ** 31 and (cp, cout) == (72, 32):
+                # weight gradient on the LDS-staged tiles as well (output-channel-major scratch, see the unpack below)
+                ops.conv3x3_direct_wgrad(cat, w.dpre_f[j], w.dWt[i], B=B, H=r, W=r, cin_pad=cp, ldx=cp, cout=cout, ldy=cout)
+                w.wgrad_n_major = True
+            else:
+                if j == 3:
+                    w.wgrad_n_major = False
+                self._wgrad(w, i, cat, r, cp, cp, r, 1, w.dpre_f[j], cout)
             # dgrad into the concat-gradient buffer (fus3: only the 64 upsampled channels carry gradient)
             ncols = FUS_OUT[2] if j == 3 else cp
             dcat = w.dcat[j]
@@ -752,7 +759,8 @@ class HipEngine:
                          conv=(r_out, r_out, cout, cout, r_in, r_in, 2), ldc=tgt.shape[-1], flags=ACCUM_BF16)
         # conv weight gradients: dWt [(ky,kx,c_pad), cout] -> parameter layout [cout, cin, ky, kx]
         for i, cv in enumerate(convs):
-            ops.unpack_conv3x3_wgrad(w.dWt[i], fl.gview[id(cv.conv.weight)], pk.cin_pad[i], rot=3 if pk.perm[i] is not None else 0)
+            ops.unpack_conv3x3_wgrad(w.dWt[i], fl.gview[id(cv.conv.weight)], pk.cin_pad[i], rot=3 if pk.perm[i] is not None else 0,
+                                     n_major=(i == len(convs) - 1 and getattr(w, "wgrad_n_major", False)))
         if on_decoder_done is not None:
             on_decoder_done()
         # ---- encoder (LoRA gradients; frozen weights need dgrad only)

@@ -153,10 +153,18 @@ def lora_pack(lora_flat, AcatT, Acat, B2, Bqv, L, D, r, alpha):
     _call("mvit_lora_pack", _p(lora_flat), _p(AcatT), _p(Acat), _p(B2), _p(Bqv), L, D, r, float(alpha))
 
 
-def unpack_conv3x3_wgrad(dWt, dW, cin_pad, rot=0, accumulate=False):
+def unpack_conv3x3_wgrad(dWt, dW, cin_pad, rot=0, accumulate=False, n_major=False):
     cout, cin = dW.shape[0], dW.shape[1]
     assert dWt.dtype == torch.float32 and dW.dtype == torch.float32 and dW.is_contiguous()
-    _call("mvit_unpack_conv3x3_wgrad", _p(dWt), _p(dW), cout, cin, cin_pad, rot, int(accumulate))
+    _call("mvit_unpack_conv3x3_wgrad", _p(dWt), _p(dW), cout, cin, cin_pad, rot, int(accumulate), int(n_major))
+
+
+def conv3x3_direct_wgrad(x, dy, dwn, *, B, H, W, cin_pad, ldx, cout, ldy):
+    """dwn [cout, 9*cin_pad] f32 += weight gradient of the stride-1 3x3 convolution (LDS-staged tiles, contraction over pixels)"""
+    _chk_bf16(x, "x")
+    _chk_bf16(dy, "dy")
+    assert dwn.dtype == torch.float32 and dwn.numel() == cout * 9 * cin_pad
+    _call("mvit_conv3x3_direct_wgrad", _p(x), _p(dy), _p(dwn), B, H, W, cin_pad, ldx, cout, ldy)
 
 
 def layernorm_bwd(dh, x, w, dx, gamma_next=None, dy=None, eps=1e-6, accumulate=True, rowscale_next=None):

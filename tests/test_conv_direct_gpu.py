@@ -69,6 +69,31 @@ def test_direct_conv_input_gradient_of_the_last_fusion_block(B, H, W):
     assert _rel(dx.float(), ref) < 4e-3
 
 
+@pytest.mark.parametrize("B,H,W,cin,cp,rot", [(2, 256, 256, 67, 72, 3), (3, 37, 45, 67, 72, 0), (2, 64, 96, 3, 8, 0), (2, 48, 64, 32, 32, 0)])
+def test_direct_conv_weight_gradient(B, H, W, cin, cp, rot):
+    """dW of the stride-1 3x3 conv from LDS-staged X / dY tiles (contraction over pixels), through the n-major unpack"""
+    import miphei_vit_amd.ops as ops
+    cout = 32
+    x = _rand(B, H, W, cin, seed=2).bfloat16()
+    dy = _rand(B, H, W, cout, seed=3).bfloat16()
+    xb = torch.zeros(B, H, W, cp, device="cuda", dtype=torch.bfloat16)
+    perm = (torch.arange(cin, device="cuda") + rot) % cin
+    xb[..., :cin] = x[..., perm]
+    dwn = torch.zeros(cout, 9 * cp, device="cuda")
+    ops.conv3x3_direct_wgrad(xb, dy, dwn, B=B, H=H, W=W, cin_pad=cp, ldx=cp, cout=cout, ldy=cout)
+    dW = torch.empty(cout, cin, 3, 3, device="cuda")
+    ops.unpack_conv3x3_wgrad(dwn, dW, cp, rot=rot, n_major=True)
+    w = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    assert _rel(dW, w.grad) < 2e-3
+    # against the TN-GEMM path it replaces
+    dWt = torch.zeros(9 * cp, cout, device="cuda")
+    ops.gemm_tn(xb, dy, dWt, M=B * H * W, I=9 * cp, J=cout, ldb=cout, ldci=cout, msplit=8, conv=(H, W, cp, cp, H, W, 1))
+    dW2 = torch.empty_like(dW)
+    ops.unpack_conv3x3_wgrad(dWt, dW2, cp, rot=rot)
+    assert _rel(dW, dW2) < 2e-3
+
+
 def test_direct_conv_rejects_unsupported_shapes():
     import miphei_vit_amd.ops as ops
     assert not ops.conv3x3_direct_supported(176, 64) and not ops.conv3x3_direct_supported(72, 48)

@@ -143,3 +143,6 @@ def test_lora_pack_and_conv_wgrad_unpack():
         assert torch.equal(dW, want)
         ops.unpack_conv3x3_wgrad(dWt, dW, cp, rot=rot, accumulate=True)
         assert torch.allclose(dW, 2 * want)
+        dwn = dWt.view(9, cp, cout).permute(2, 0, 1).contiguous()       # the direct kernel's output-channel-major layout
+        ops.unpack_conv3x3_wgrad(dwn, dW, cp, rot=rot, n_major=True)
+        assert torch.equal(dW, want)
