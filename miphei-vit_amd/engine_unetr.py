@@ -34,12 +34,139 @@ class UnetrEngine:
         self._ws = {}
         self._saved = None
         self._drop_step = 0          # dropout masks are functions of (seed, step, layer, element): nothing is stored
+        self._flat = None            # fused step: flat f32 buffer of the trainable parameters outside the ViT (+ gradient twin)
+        self._opt_stash = None
+        self._nonfinite = None
 
     def invalidate(self):
+        if self._flat is not None and self._flat.m is not None:
+            self._opt_stash = self.optimizer_state_dict()
+        self._flat = None
         self._ws = {}
         self._saved = None
         if self._enc is not None:
             self._enc.invalidate()
+
+    # ------------------------------------------------------------------ fused training step (flat buffers, one clip + Adam)
+    def _ensure_flat(self):
+        """Trainable parameters outside the ViT (pyramids, decoder, heads) in one flat f32 buffer with a gradient twin, as
+        HipEngine does for MIPHEI-ViT; the LoRA adapters live in the encoder engine's own flat buffer."""
+        if self._flat is not None:
+            return self._flat
+        enc = self._encoder_engine()
+        dev = enc._require_gpu()
+        vit_ids = {id(p) for p in self.model.encoder.model.parameters()}
+        named = [(k, p) for k, p in self.model.named_parameters() if p.requires_grad and id(p) not in vit_ids]
+        n = sum(p.numel() for _, p in named)
+        flat, gflat = torch.empty(n, device=dev), torch.zeros(n, device=dev)
+        gview, o = {}, 0
+        for _, p in named:
+            if p.dtype != torch.float32:
+                raise RuntimeError("training needs fp32 master parameters")
+            k = p.numel()
+            flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + k].view(p.shape)
+            gview[id(p)] = gflat[o:o + k].view(p.shape)
+            p.grad = gview[id(p)]
+            o += k
+        self._flat = NS(flat=flat, gflat=gflat, n=n, gview=gview, m=None, v=None, step=0, layout=[(k, p.numel()) for k, p in named])
+        if self._opt_stash is not None:
+            self.load_optimizer_state_dict(self._opt_stash)
+            self._opt_stash = None
+        return self._flat
+
+    def lora_blocks(self):
+        return self._encoder_engine().lora_blocks()
+
+    def grad_buckets(self):
+        """(decoder-side gradients, LoRA gradients): the two contiguous regions the data-parallel exchange all-reduces"""
+        return self._ensure_flat().gflat, self._encoder_engine().grad_buckets()[1]
+
+    def param_buffers(self):
+        return [self._ensure_flat().flat, self._encoder_engine()._ensure_flat().flat]
+
+    def grad_buffers(self):
+        return [self._ensure_flat().gflat, self._encoder_engine()._ensure_flat().gflat]
+
+    @property
+    def _pack_key(self):
+        return self._encoder_engine()._pack_key
+
+    @_pack_key.setter
+    def _pack_key(self, v):
+        self._encoder_engine()._pack_key = v
+
+    def nonfinite_flag(self):
+        dev = self._encoder_engine()._require_gpu()
+        if self._nonfinite is None or self._nonfinite.device != dev:
+            self._nonfinite = torch.zeros(1, device=dev, dtype=torch.int32)
+        return self._nonfinite
+
+    def loss_and_grad(self, out, target, marker_weights, lambda_factor):
+        w = self._saved.w
+        w.scal.zero_()
+        ops.wmse_fwd_bwd(out, target.to(torch.float32).contiguous(), marker_weights, w.loss_acc, w.dY, float(lambda_factor))
+        B, C, H, W = out.shape
+        return w.loss_acc * (float(lambda_factor) / (C * B * H * W)), w.dY
+
+    def backward_fused(self, dY, on_decoder_done=None, on_lora_block_done=None):
+        """Gradients straight into the flat gradient buffers (decoder side here, LoRA in the encoder engine's)."""
+        fl, efl = self._ensure_flat(), self._encoder_engine()._ensure_flat()
+        fl.gflat.zero_()
+        efl.gflat.zero_()
+        grads = self.backward(dY, fused=True, on_decoder_done=on_decoder_done, on_lora_block_done=on_lora_block_done)
+        return grads
+
+    def adam_step(self, lr, betas=(0.5, 0.999), eps=1e-7, max_norm=1.0):
+        fl, efl, w = self._flat, self._encoder_engine()._flat, self._saved.w
+        for f in (fl, efl):
+            if f.m is None:
+                f.m, f.v = torch.zeros_like(f.flat), torch.zeros_like(f.flat)
+            f.step += 1
+        ops.sqnorm(fl.gflat, w.sqn)           # one global norm over both buffers (w.sqn was zeroed in loss_and_grad)
+        ops.sqnorm(efl.gflat, w.sqn)
+        for f in (fl, efl):
+            ops.adam_clip_step(f.flat, f.gflat, f.m, f.v, w.sqn, float(lr), betas[0], betas[1], eps, 1.0 - betas[0] ** f.step,
+                               1.0 - betas[1] ** f.step, float(max_norm), nonfinite=self.nonfinite_flag())
+        self._encoder_engine()._pack_key = None
+        return w.sqn
+
+    def optimizer_state_dict(self):
+        fl, enc = self._flat, self._encoder_engine()
+        if fl is None or fl.m is None:
+            return self._opt_stash if self._opt_stash is not None else {"step": 0, "exp_avg": None, "exp_avg_sq": None, "layout": None}
+        e = enc.optimizer_state_dict()
+        return {"step": int(fl.step), "exp_avg": torch.cat([fl.m, e["exp_avg"]]), "exp_avg_sq": torch.cat([fl.v, e["exp_avg_sq"]]),
+                "layout": [tuple(x) for x in fl.layout] + [tuple(x) for x in e["layout"]]}
+
+    def load_optimizer_state_dict(self, sd):
+        if sd is None or sd.get("exp_avg") is None:
+            return
+        if self._flat is None:
+            self._opt_stash = sd
+            return
+        fl, enc = self._flat, self._encoder_engine()
+        efl = enc._ensure_flat()
+        want = [tuple(x) for x in fl.layout] + [tuple(x) for x in efl.layout]
+        if [tuple(x) for x in sd["layout"]] != want:
+            raise RuntimeError("optimizer state does not match the trainable parameters of this generator")
+        dev = fl.flat.device
+        fl.m, fl.v = sd["exp_avg"][:fl.n].to(dev).clone(), sd["exp_avg_sq"][:fl.n].to(dev).clone()
+        efl.m, efl.v = sd["exp_avg"][fl.n:].to(dev).clone(), sd["exp_avg_sq"][fl.n:].to(dev).clone()
+        fl.step = efl.step = int(sd["step"])
+
+    def capture_inference(self, batch):
+        """hipGraph capture of the eval-mode forward for a fixed batch (as HipEngine.capture_inference)."""
+        enc = self._encoder_engine()
+        dev = enc._require_gpu()
+        c = enc._config()
+        x_static = torch.zeros(batch, 3, c.S, c.S, device=dev, dtype=torch.float32)
+        self._forward(x_static, train=False)          # warm-up: allocations, packs, LDS attributes
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out_static = self._forward(x_static, train=False)
+        return graph.replay, x_static, out_static
 
     def _encoder_engine(self):
         if self._enc is None:
@@ -148,6 +275,9 @@ class UnetrEngine:
             w.dXc = e(Mp, HEAD_C, dt=torch.float32)
             w.dW3 = e(NH * 9, HEAD_C, dt=torch.float32)
             w.db3_slots = z(64, 32, dt=torch.float32)
+            w.scal = z(2, dt=torch.float64)          # loss accumulator | gradient square norm (fused step)
+            w.loss_acc, w.sqn = w.scal[0:1], w.scal[1:2]
+            w.dY = e(B, NH, S, S, dt=torch.float32)
         self._ws[key] = w
         return w
 
@@ -213,8 +343,11 @@ class UnetrEngine:
         st[name] = NS(wt=wt)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x):
+    def forward(self, x, train=None):
         m = self.model
+        if train:        # fused step (ModelModule.training_step): no autograd graph, gradients go to the flat buffers
+            self._ensure_flat()
+            return self._forward(x, train=True)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters())
         if not needs_grad or not m.training:
             # eval mode never records a graph (backward through eval-mode BatchNorm is not part of the training path)
@@ -301,8 +434,10 @@ class UnetrEngine:
         return w.out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dY):
-        """-> {id(param): gradient tensor} for every trainable parameter of the generator"""
+    def backward(self, dY, fused=False, on_decoder_done=None, on_lora_block_done=None):
+        """-> {id(param): gradient tensor} for every trainable parameter of the generator.  fused: the decoder-side gradients
+        are also written into the flat gradient buffer and the LoRA gradients stay in the encoder engine's (no copies handed
+        out); the hooks are those of HipEngine.backward (data-parallel exchange)."""
         sv = self._saved
         if sv is None:
             raise RuntimeError("backward() needs a preceding training-mode forward")
@@ -366,15 +501,24 @@ class UnetrEngine:
                            ld_dst=D, src_bstride=G * G * D, dst_bstride=c.ntok * D)
         where = {l: i for i, l in enumerate(layers)}
         assert layers[-1] == c.L - 1
-        keep = fl.gflat.clone()     # LoRA .grad tensors are views of the flat gradient buffer: hand out copies, restore
-        fl.gflat.zero_()
+        if fused:
+            gv = self._flat.gview
+            for pid, g in grads.items():          # decoder-side gradients into their slices of the flat gradient buffer
+                gv[pid].copy_(g.reshape(gv[pid].shape))
+            if on_decoder_done is not None:
+                on_decoder_done()
+        else:
+            keep = fl.gflat.clone() # LoRA .grad tensors are views of the flat gradient buffer: hand out copies, restore
+            fl.gflat.zero_()
         we.dx.copy_(we.dtap[3])
 
         def inject(l):
             if l in where:
                 we.dx.add_(we.dtap[where[l]])
 
-        enc._encoder_bwd(we, pk, fl, fz, from_tokens=False, inject=inject)
+        enc._encoder_bwd(we, pk, fl, fz, from_tokens=False, inject=inject, on_block_done=on_lora_block_done if fused else None)
+        if fused:
+            return grads
         new = fl.gflat.clone()
         fl.gflat.copy_(keep)
         o = 0

@@ -112,8 +112,8 @@ class ModelModule(_Base):
             w = self.loss_reconstruct.marker_weights
         loss, dY = eng.loss_and_grad(out, y.to(out.device), w, self.loss_reconstruct.lambda_factor)
         sync = self.grad_sync
-        eng.backward(dY, on_decoder_done=(sync.decoder_ready if sync is not None else None),
-                     on_lora_block_done=(sync.lora_block_done if sync is not None else None))
+        getattr(eng, "backward_fused", eng.backward)(dY, on_decoder_done=(sync.decoder_ready if sync is not None else None),
+                                                     on_lora_block_done=(sync.lora_block_done if sync is not None else None))
         if sync is not None:
             sync.finish()
         eng.adam_step(self.current_lr(), betas=(0.5, 0.999), eps=1e-7, max_norm=1.0)
@@ -125,10 +125,10 @@ class ModelModule(_Base):
         return loss
 
     def _training_step_autograd(self, x, y):
-        """The reference's own sequence (models.py:87-143) for generators without the fused step (UNETR baseline): forward and
-        backward through the autograd bridge of the HIP engine, torch global-norm clip, torch Adam + LambdaLR."""
+        """The reference's own sequence (models.py:87-143) for losses other than WeightedMSELoss: forward and backward through the
+        autograd bridge of the HIP engine, torch global-norm clip, torch Adam + LambdaLR."""
         if self.grad_sync is not None:
-            raise NotImplementedError("multi-GPU gradient exchange is wired into the fused MIPHEI-ViT step only")
+            raise NotImplementedError("multi-GPU gradient exchange is wired into the fused step (WeightedMSELoss) only")
         if getattr(self, "_opt", None) is None:
             opts, scheds = self.configure_optimizers()
             self._opt, self._sched = opts[0], scheds[0]["scheduler"]

@@ -36,10 +36,18 @@ class DataParallelSync:
         self._work = []
         self._ranges = None
 
+    def _buffers(self, kind):
+        """flat parameter / gradient buffers of the engine (MIPHEI-ViT: one; UNETR baseline: decoder side + LoRA)"""
+        get = getattr(self.engine, kind + "_buffers", None)
+        if get is not None:
+            return get()
+        fl = self.engine._ensure_flat()
+        return [fl.flat if kind == "param" else fl.gflat]
+
     def broadcast_parameters(self, src=0):
         if self.active:
-            fl = self.engine._ensure_flat()
-            dist.broadcast(fl.flat, src=src, group=self.group)
+            for buf in self._buffers("param"):
+                dist.broadcast(buf, src=src, group=self.group)
             self.engine._pack_key = None
 
     def _issue(self, t):
@@ -80,7 +88,8 @@ class DataParallelSync:
             wk.wait()
         self._work = []
         if self.world > 1:
-            self.engine._ensure_flat().gflat.mul_(1.0 / self.world)
+            for buf in self._buffers("grad"):
+                buf.mul_(1.0 / self.world)
         if self.timing:
             e1.record()
             self.exposed_events.append((e0, e1))

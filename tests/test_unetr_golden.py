@@ -312,3 +312,59 @@ def test_get_generator_unet_lora_accepts_the_shipped_dropout():
     with pytest.raises(ValueError):
         from miphei_vit_amd.generators.unet import Unet
         Unet(128, "tiny4", classes=3, pretrained=False, drop_rate=1.0)
+
+
+@pytest.mark.gpu
+def test_unetr_fused_step_matches_autograd_bridge_and_hipgraph_inference(golden_dir):
+    """ModelModule.training_step on the UNETR baseline runs the fused sequence (flat gradient buffers, one global-norm clip + Adam
+    kernel pair): same parameters after a step as the reference's own sequence through the autograd bridge + torch clip / Adam;
+    the optimiser state survives a re-flatten; the eval forward replays from a hipGraph."""
+    from oracle import synth_batch
+    from oracle.model import orion_marker_weights
+    from miphei_vit_amd.generators.unet import Unet
+    from miphei_vit_amd.loss import WeightedMSELoss
+    from miphei_vit_amd.models import ModelModule
+    g, cfg, p, img, nc, B, seed = _load(golden_dir, "tiny4_swiglu_p14_128")
+    w = orion_marker_weights(16)[:nc]
+
+    def make():
+        model = Unet(img, str(g["cfg"]), use_lora=True, classes=nc, pretrained=False)
+        model.load_state_dict(p)
+        mod = ModelModule(model.cuda(), None, 0.05, 0.0, WeightedMSELoss(50.0, w)).cuda()
+        mod.total_iters = 1000             # warm-up: lr = 0.05 * step / 400 (the torch LambdaLR of the bridge path starts at step 0 too)
+        return mod, model
+
+    x, y = synth_batch(seed, B, img, nc)
+    batch = {"image": x.cuda(), "target": y.cuda()}
+    fused, mf = make()
+    ref, mr = make()
+    for it in range(2):                    # step 0 runs at lr 0, step 1 moves the parameters
+        l1 = float(fused.training_step(batch, it))
+        l2 = float(ref._training_step_autograd(batch["image"], batch["target"]))   # autograd bridge + torch clip + torch Adam
+        assert abs(l1 - l2) < 1e-4 * abs(l2)
+    assert mf._engine._flat is not None and mf._engine._flat.step == 2          # the fused path ran
+    a, b = dict(mf.named_parameters()), dict(mr.named_parameters())
+    for k in a:
+        if not a[k].requires_grad:
+            continue
+        moved = float((b[k].detach().cpu() - p[k]).double().norm())
+        d = float((a[k].detach() - b[k].detach()).double().norm())
+        # same gradients, same Adam rule; Adam's sign-like first steps turn the f32-atomics noise of near-zero gradient
+        # components into +-lr flips of single elements, so the displacement is compared in norm
+        assert d <= 0.2 * moved + 1e-7, (k, d, moved)
+    assert float((b["decoder.decoder0_header.2.weight"].detach().cpu() - p["decoder.decoder0_header.2.weight"]).abs().max()) > 1e-5
+    # state survives .cuda() / load_state_dict, second step continues with step count 2
+    mf.cuda()
+    assert mf._engine._flat is None
+    fused.training_step(batch, 2)
+    assert mf._engine._flat.step == 3 and mf._engine._encoder_engine()._flat.step == 3
+    sd = mf._engine.optimizer_state_dict()
+    assert sd["step"] == 3 and sd["exp_avg"].numel() == sum(n for _, n in sd["layout"])
+    # hipGraph inference
+    mf.eval()
+    run, xs, out_static = mf._engine.capture_inference(B)
+    xs.copy_(batch["image"])
+    run()
+    with torch.no_grad():
+        eager = mf(batch["image"])
+    assert torch.equal(out_static, eager)
