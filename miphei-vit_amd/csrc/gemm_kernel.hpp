@@ -55,6 +55,9 @@ constexpr size_t gemm_lds_bytes() {
 #ifndef MVIT_GEMM_PREISSUE
 #define MVIT_GEMM_PREISSUE 1
 #endif
+#ifndef MVIT_GEMM_TRANS   // 1: dense tiles accumulate C^T (MFMA operands swapped) and store row-per-lane, no LDS panel
+#define MVIT_GEMM_TRANS 1
+#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit_gemm_args p) {
@@ -75,6 +78,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // register-double-buffered fragment pipeline with an explicit instruction order: one wave per SIMD (4 waves, 128-row
   // sub-tiles) and, with MVIT_GEMM_PIPE8, the 8-wave 256-row tiles too
   constexpr bool PIPE = (NW == 4 && WTM == 128) || (MVIT_GEMM_PIPE8 && NW == 8 && BM == 256);
+  // Transposed accumulation: acc[i][j] holds D^T (lane = row of C, registers = 4-column groups), so the epilogue needs no
+  // transposition through LDS: every lane post-processes and stores pieces of its own row.
+  constexpr bool TRANS = MVIT_GEMM_TRANS && AMODE == MVIT_A_DENSE && EPI == MVIT_EPI_STORE;
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
   static_assert((size_t)NW * SLAB * 4 + (size_t)WAVES_M * BN * 8 <= (size_t)BUF_BYTES, "epilogue panel must fit one LDS buffer");
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -354,7 +360,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i], xb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[j], xa[i], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i], xb[j], acc[i][j], 0, 0, 0);
       };
       auto wait_tile = [&](int tn) __attribute__((always_inline)) {  // this lane's DMA pieces of K tile tn have landed
         if (NSTAGE == 3 && tn + 1 < t_end)
@@ -411,7 +418,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #if MVIT_ABLATE & 4
           asm volatile("" ::"v"(ca[i]), "v"(cbf[j]));
 #else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], cbf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(cbf[j], ca[i], acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], cbf[j], acc[i][j], 0, 0, 0);
 #endif
 #pragma unroll
           for (int c = 0; c < NR + PG; ++c) {
@@ -584,7 +592,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
       cb = cb + 1 == NSTAGE ? 0 : cb + 1;
       ib = ib + 1 == NSTAGE ? 0 : ib + 1;
@@ -711,6 +720,93 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
     };
 
+    if constexpr (TRANS) {
+      // D^T layout of the 32x32 MFMA: lane & 31 = row of C inside the 32-row block, register r = column (r&3) + 8*(r>>2) + 4*half.
+      // bf16: the two half-waves hold interleaved 4-column groups of the same rows; v_permlane32_swap pairs them into 8
+      // consecutive columns per lane -> 16-byte stores (cdna_hip_programming.md T21).
+      if (!(p.flags & 0x800)) {
+        float4 b4[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c0 = en0 + wave_n * WTN + j * 32 + 8 * q + 4 * frag_half;
+            b4[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) {
+              if (c0 + 3 < p.N && !scalar_io) {
+                b4[j][q] = *(const float4*)(p.bias + c0);
+              } else {
+                b4[j][q].x = c0 < p.N ? p.bias[c0] : 0.f, b4[j][q].y = c0 + 1 < p.N ? p.bias[c0 + 1] : 0.f;
+                b4[j][q].z = c0 + 2 < p.N ? p.bias[c0 + 2] : 0.f, b4[j][q].w = c0 + 3 < p.N ? p.bias[c0 + 3] : 0.f;
+              }
+            }
+          }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = em0 + wave_m * WTM + i * 32 + frag_row;
+          const bool rok = row < p.M;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int cb0 = en0 + wave_n * WTN + j * 32;
+            const bool fast = !scalar_io && !atomic && !out_f32 && cb0 + 32 <= p.N;
+            if (fast) {
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {      // group pairs (0,1) and (2,3)
+                const int q0 = 2 * pr, q1 = 2 * pr + 1;
+                unsigned a0 = pack2bf(acc[i][j][4 * q0] + b4[j][q0].x, acc[i][j][4 * q0 + 1] + b4[j][q0].y);
+                unsigned a1 = pack2bf(acc[i][j][4 * q0 + 2] + b4[j][q0].z, acc[i][j][4 * q0 + 3] + b4[j][q0].w);
+                unsigned c0 = pack2bf(acc[i][j][4 * q1] + b4[j][q1].x, acc[i][j][4 * q1 + 1] + b4[j][q1].y);
+                unsigned c1 = pack2bf(acc[i][j][4 * q1 + 2] + b4[j][q1].z, acc[i][j][4 * q1 + 3] + b4[j][q1].w);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1, false, false);
+                // lanes 0-31: columns 16*pr + 0..7, lanes 32-63: columns 16*pr + 8..15 of the block
+                uint4 o4 = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                if (rok) {
+                  bf16_t* dst = Cb + (size_t)row * p.ldc + cb0 + 16 * pr + 8 * frag_half;
+                  if (p.flags & MVIT_ACCUM_BF16) {
+                    const uint4 old = *(const uint4*)dst;
+                    const uint32_t uo[4] = {old.x, old.y, old.z, old.w}, un[4] = {o4.x, o4.y, o4.z, o4.w};
+                    uint32_t r_[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                      r_[e] = pack2bf(__uint_as_float(uo[e] << 16) + __uint_as_float(un[e] << 16),
+                                      __uint_as_float(uo[e] & 0xffff0000u) + __uint_as_float(un[e] & 0xffff0000u));
+                    o4 = make_uint4(r_[0], r_[1], r_[2], r_[3]);
+                  }
+                  *(uint4*)dst = o4;
+                }
+              }
+            } else if (rok) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int c0 = cb0 + 8 * q + 4 * frag_half;
+                const float v[4] = {acc[i][j][4 * q] + b4[j][q].x, acc[i][j][4 * q + 1] + b4[j][q].y, acc[i][j][4 * q + 2] + b4[j][q].z,
+                                    acc[i][j][4 * q + 3] + b4[j][q].w};
+                const size_t o = (size_t)row * p.ldc + c0;
+                if (atomic) {
+                  for (int e = 0; e < 4; ++e)
+                    if (c0 + e < p.N) atomicAdd(Cf + o + e, v[e]);
+                } else if (out_f32) {
+                  if (c0 + 3 < p.N && !scalar_io) {
+                    *(float4*)(Cf + o) = make_float4(v[0], v[1], v[2], v[3]);
+                  } else {
+                    for (int e = 0; e < 4; ++e)
+                      if (c0 + e < p.N) Cf[o + e] = v[e];
+                  }
+                } else {
+                  for (int e = 0; e < 4; ++e)
+                    if (c0 + e < p.N) {
+                      float t_ = v[e];
+                      if (p.flags & MVIT_ACCUM_BF16) t_ += bf2f(Cb[o + e]);
+                      Cb[o + e] = f2bf(t_);
+                    }
+                }
+              }
+            }
+          }
+        }
+      }
+    } else
     if (!(p.flags & 0x800)) {  // (0x800: debug, no epilogue)
       issue_aux(0, 0);
 #pragma unroll
