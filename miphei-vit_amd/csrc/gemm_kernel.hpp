@@ -80,6 +80,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr bool PIPE = (NW == 4 && WTM == 128) || (MVIT_GEMM_PIPE8 && NW == 8 && BM == 256);
   // Transposed accumulation: acc[i][j] holds D^T (lane = row of C, registers = 4-column groups), so the epilogue needs no
   // transposition through LDS: every lane post-processes and stores pieces of its own row.
+  // (Measured and dropped for the epilogues with per-element operands -- residual, SwiGLU, d(SwiGLU): a lane per row means 64
+  // different cache lines per load / store instruction, and proj + residual went 39 -> 48 us, dfc2 + d(SwiGLU) 84 -> 100 us.)
   constexpr bool TRANS = MVIT_GEMM_TRANS && AMODE == MVIT_A_DENSE && EPI == MVIT_EPI_STORE;
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
   static_assert((size_t)NW * SLAB * 4 + (size_t)WAVES_M * BN * 8 <= (size_t)BUF_BYTES, "epilogue panel must fit one LDS buffer");
