@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
 // ------------------------------------------------------------------ LayerNorm backward (input grad only)
 // dx (+)= rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * w.  Statistics are recomputed from x.
 // Optionally emits dy = bf16(gamma_next * dx_total): the LayerScale-scaled gradient the next dgrad GEMM consumes.
+template <int NV>  // float4 groups per lane (D <= 256 * NV): the three row images below are 12 * NV registers
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dh, const float* __restrict__ x,
                                                      const float* __restrict__ w, float* __restrict__ dx,
                                                      const float* __restrict__ gamma_next, bf16_t* __restrict__ dy,
@@ -165,11 +166,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   const int nv = D >> 2;
   const float4* xr = (const float4*)(x + (size_t)row * D);
   const uint2* gr = (const uint2*)(dh + (size_t)row * D);
-  float4 v[LN_MAXV], g[LN_MAXV], o[LN_MAXV];
+  float4 v[NV], g[NV], o[NV];
   float4* dxr = (float4*)(dx + (size_t)row * D);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
     if (idx < nv) {
       v[i] = xr[idx];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   const float mu = wave_sum(s) / D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
     if (idx < nv) {
       v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   const float rs = rsqrtf(wave_sum(q) / D + eps);
   float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
     if (idx < nv) {
       v[i].x *= rs; v[i].y *= rs; v[i].z *= rs; v[i].w *= rs;  // xhat
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   c2 = wave_sum(c2) / D;
   uint2* dyr = dy ? (uint2*)(dy + (size_t)row * D) : nullptr;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
     if (idx < nv) {
       float4 r;
@@ -387,9 +388,15 @@ MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, 
   MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
   if ((dy != nullptr) != (gamma_next != nullptr)) return MVIT_EINVAL;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, x, w, dx,
-                     gamma_next, (bf16_t*)dy, M, D, eps, accumulate, rowscale_next);
-  return MVIT_LAUNCH_CHECK();
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, x, w, dx, gamma_next,
+                       (bf16_t*)dy, M, D, eps, accumulate, rowscale_next);
+    return MVIT_LAUNCH_CHECK();
+  };
+  if (D <= 512) return launch(ln_bwd_kernel<2>);
+  if (D <= 1024) return launch(ln_bwd_kernel<4>);
+  if (D <= 1536) return launch(ln_bwd_kernel<6>);
+  return launch(ln_bwd_kernel<8>);
 }
 
 MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void* out, int ldo, int M, int K, int R,

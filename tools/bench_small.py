@@ -54,3 +54,8 @@ dwn = torch.zeros(cout, 9 * cp, device="cuda")
 dwt = torch.zeros(9 * cp, cout, device="cuda")
 print(f"fus3 wgrad direct      {timeit(lambda: ops.conv3x3_direct_wgrad(xb, dy, dwn, B=B, H=S, W=S, cin_pad=cp, ldx=cp, cout=cout, ldy=cout)):7.1f} us")
 print(f"fus3 wgrad TN GEMM     {timeit(lambda: ops.gemm_tn(xb, dy, dwt, M=B*S*S, I=9*cp, J=cout, ldb=cout, ldci=cout, msplit=170, conv=(S, S, cp, cp, S, S, 1))):7.1f} us", flush=True)
+dh = torch.randn(M, D, device="cuda").to(bf)
+dx = torch.randn(M, D, device="cuda")
+gam = torch.randn(D, device="cuda")
+dyb = torch.empty(M, D, device="cuda", dtype=bf)
+print(f"ln_bwd                 {timeit(lambda: ops.layernorm_bwd(dh, x, w, dx, gam, dyb, 1e-6, True)):7.1f} us   (128 MB algorithmic)")
