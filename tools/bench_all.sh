@@ -19,13 +19,16 @@ MIPHEI_FORCE_DDP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 python3 bench.py --no
 rocprofv3 --kernel-trace --stats -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 tools/step_counters.py $O/trace $O/pmc_sq $O/pmc_fetch $O/pmc_write > $O/step_counters.txt 2> $O/step_counters.err
 db=$(ls $O/stats/*/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python3 tools/prof_summary.py $db 70 > $O/kernel_stats_train.txt
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > $O/pmc_traffic.txt
 if [ "${COPY:-1}" = 1 ]; then
-  for f in $O/bench_*.json $O/kernel_stats_train.txt $O/pmc_traffic.json; do
+  for f in $O/bench_*.json $O/kernel_stats_train.txt $O/pmc_traffic.json $O/step_counters.txt; do
     [ -s "$f" ] && cp $f profiles/${R}_$(basename $f)
   done
 fi
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write      # raw traces are large; the summaries above are what is kept
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/trace $O/pmc_sq      # raw traces are large; the summaries above are what is kept
 for f in $O/bench_*.json; do echo "== $f"; cut -c1-400 $f; done; head -25 $O/kernel_stats_train.txt; cat $O/pmc_traffic.txt
