@@ -101,6 +101,7 @@ def parse_args(argv=None):
     ap.add_argument("--metrics", type=int, default=0, help="train mode: also run the per-step PSNR/SSIM state update of the "
                     "reference (models.py:140-143); the headline number is taken with it off (SURVEY.md section 6)")
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
+    ap.add_argument("--lora-group", type=int, default=0, help="ViT blocks per batched LoRA weight-gradient launch (0 = engine default)")
     ap.add_argument("--lora-buckets", type=int, default=4, help="sub-buckets of the LoRA gradient all-reduce (N > 1)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL; gloo only with --dry")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher / rendezvous / exchange / timing protocol on CPU")
@@ -252,6 +253,8 @@ def main(argv=None):
             model = get_vitmatte("tiny" if a.mode == "embed" else a.encoder, a.img, nc, use_lora=True, pretrained=False)
     synthetic_init_(model, seed=0)
     eng = model._engine
+    if a.lora_group > 0:
+        (eng._encoder_engine() if hasattr(eng, "_encoder_engine") else eng).lora_group = a.lora_group
     if unet and not hasattr(eng, "capture_inference"):
         a.graph = 0
     mod = ModelModule(model, None, 2e-4 * a.batch ** 0.5, 0., WeightedMSELoss(50.0, weights)).to(dev)

@@ -88,7 +88,12 @@ typedef struct mvit_gemm_tn_args {
    * the columns are split too: rows < isplit keep columns j < j1 (in C), rows >= isplit keep columns j >= jlo2
    * (C2, column j - jlo2), everything else is dropped - the two LoRA adapters' dB from one pass over [dq | dk | dv]. */
   float* C2;
-  int isplit, j1, jlo2, pad_;
+  int isplit, j1, jlo2;
+  /* batch > 1 (dense A only): `batch` independent products from one launch; product b reads A + b*strideA, B + b*strideB
+   * and accumulates into C + b*strideC (and C2 + b*strideC), strides in elements - the LoRA weight gradients of a group of
+   * ViT blocks, whose per-block launches (4 steps of m each) are latency-bound. */
+  int batch;
+  long long strideA, strideB, strideC;
 } mvit_gemm_tn_args;
 MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_stream_t stream);
 

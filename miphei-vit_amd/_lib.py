@@ -36,7 +36,8 @@ class GemmTnArgs(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("ldci", ll), ("ldcj", ll),
                 ("M", ci), ("I", ci), ("J", ci), ("lda", ci), ("ldb", ci), ("amode", ci), ("msplit", ci),
                 ("conv_H", ci), ("conv_W", ci), ("conv_C", ci), ("conv_ld", ci), ("conv_OH", ci), ("conv_OW", ci),
-                ("conv_stride", ci), ("C2", vp), ("isplit", ci), ("j1", ci), ("jlo2", ci), ("pad_", ci)]
+                ("conv_stride", ci), ("C2", vp), ("isplit", ci), ("j1", ci), ("jlo2", ci), ("batch", ci),
+                ("strideA", ll), ("strideB", ll), ("strideC", ll)]
 
 
 # name -> argtypes (restype is always int); mirrors include/miphei_hip.h

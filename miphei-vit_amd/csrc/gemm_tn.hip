@@ -53,12 +53,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
   const int half = lane >> 5, l31 = lane & 31;
   const int i0 = blockIdx.x * IT, j0 = blockIdx.y * JT;
   const long long nsteps = ((long long)p.M + 63) / 64;
-  const long long per = (nsteps + gridDim.z - 1) / gridDim.z;
-  const long long s_begin = blockIdx.z * per, s_end = min(nsteps, s_begin + per);
+  const int nb = p.batch > 1 ? p.batch : 1;
+  const int nz = gridDim.z / nb, bi = blockIdx.z / nz, zi = blockIdx.z - bi * nz;   // (product, slice of m)
+  const long long per = (nsteps + nz - 1) / nz;
+  const long long s_begin = zi * per, s_end = min(nsteps, s_begin + per);
   if (s_begin >= s_end) return;
   if (p.C2 && p.jlo2 > 0 && j0 >= p.j1 && j0 + JT <= p.jlo2) return;  // column block owned by neither output
-  const bf16_t* Ap = (const bf16_t*)p.A;
-  const bf16_t* Bp = (const bf16_t*)p.B;
+  const bf16_t* Ap = (const bf16_t*)p.A + (size_t)bi * p.strideA;
+  const bf16_t* Bp = (const bf16_t*)p.B + (size_t)bi * p.strideB;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(AMODE == MVIT_A_DENSE ? (const void*)(Ap + (size_t)s_begin * 64 * p.lda) : (const void*)Ap);
   const __amdgpu_buffer_rsrc_t rsB = make_rsrc(Bp + (size_t)s_begin * 64 * p.ldb);
 
@@ -144,7 +146,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
     cur ^= 1;
   }
   // D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*half
-  float* C = (float*)p.C;
+  float* C = (float*)p.C + (size_t)bi * p.strideC;
+  float* C2 = p.C2 ? p.C2 + (size_t)bi * p.strideC : nullptr;
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int j = j0 + wave_j * WJT + t * 32 + l31;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
       } else if (i < p.isplit) {   // two outputs from one pass (see mvit_gemm_tn_args)
         if (p.jlo2 == 0 || j < p.j1) atomicAdd(C + (size_t)i * p.ldci + (size_t)j * p.ldcj, acc[t][r]);
       } else if (j >= p.jlo2) {
-        atomicAdd(p.C2 + (size_t)(i - p.isplit) * p.ldci + (size_t)(j - p.jlo2) * p.ldcj, acc[t][r]);
+        atomicAdd(C2 + (size_t)(i - p.isplit) * p.ldci + (size_t)(j - p.jlo2) * p.ldcj, acc[t][r]);
       }
     }
   }
@@ -169,7 +172,9 @@ int launch(const mvit_gemm_tn_args& a, hipStream_t s) {
   const long long nsteps = ((long long)a.M + 63) / 64;
   int split = a.msplit > 0 ? a.msplit : 1;
   if (split > nsteps) split = (int)nsteps;
-  dim3 grid((a.I + IT - 1) / IT, (a.J + JT - 1) / JT, split);
+  const int nb = a.batch > 1 ? a.batch : 1;
+  if ((long long)split * nb > 65535) return MVIT_EINVAL;
+  dim3 grid((a.I + IT - 1) / IT, (a.J + JT - 1) / JT, split * nb);
   const size_t lds = 2 * (size_t)(IT / 64 + (JT + 63) / 64) * BLK_BYTES;
   if (a.amode == MVIT_A_DENSE)
     hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_DENSE>), grid, dim3(256), lds, s, a);
@@ -186,6 +191,7 @@ extern "C" MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_st
   const mvit_gemm_tn_args& a = *args;
   if (a.M <= 0 || a.I <= 0 || a.J <= 0 || (a.I & 7) || (a.J & 7) || (a.ldb & 7)) return MVIT_EINVAL;
   if (a.C2 && (a.isplit <= 0 || a.isplit >= a.I || a.jlo2 < 0 || (a.jlo2 > 0 && (a.j1 <= 0 || a.j1 > a.jlo2)))) return MVIT_EINVAL;
+  if (a.batch < 0 || (a.batch > 1 && (a.amode != MVIT_A_DENSE || ((a.strideA | a.strideB) & 7)))) return MVIT_EINVAL;
   if (a.amode == MVIT_A_DENSE) {
     if (a.lda & 7) return MVIT_EINVAL;
   } else if (a.amode == MVIT_A_CONV3) {

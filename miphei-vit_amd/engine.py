@@ -54,6 +54,7 @@ class HipEngine:
         self._flat = None
         self._opt_stash = None       # Adam state carried across re-flattening (see invalidate)
         self._nonfinite = None       # device int32: sticky NaN-guard flag written by the Adam kernel
+        self.lora_group = 10         # ViT blocks whose LoRA weight-gradient products share one launch (_encoder_bwd)
         self.invalidate()
 
     # ------------------------------------------------------------------ state management
@@ -371,9 +372,13 @@ class HipEngine:
         nl = c.L if train else 1
         w.x_in = [e(M, D, dt=torch.float32) for _ in range(nl + 1)] if train else [e(M, D, dt=torch.float32)]
         w.x_mid = [e(M, D, dt=torch.float32) for _ in range(nl)]
-        w.h1 = [e(M, D) for _ in range(nl)]
+        # per-block saves of one kind sit in ONE allocation at a uniform stride: the batched LoRA weight-gradient products
+        # (_encoder_bwd) address block l's operand as base + l * stride
+        w.h1_all = e(nl, M, D)
+        w.h1 = list(w.h1_all.unbind(0))
         w.h2 = e(M, D)
-        w.t = [e(M, 2 * c.rank) for _ in range(nl)] if c.lora else None
+        w.t_all = e(nl, M, 2 * c.rank) if c.lora else None
+        w.t = list(w.t_all.unbind(0)) if c.lora else None
         w.qkv = [e(M, 3 * D) for _ in range(nl)]
         w.o = [e(M, D) for _ in range(nl)]
         w.lse = [e(B, c.H, c.ntok, dt=torch.float32) for _ in range(nl)]
@@ -460,9 +465,11 @@ class HipEngine:
         w.du = e(M, c.hidden)
         w.dh = e(M, D)
         w.do = e(M, D)
-        w.dqkv = e(M, 3 * D)
+        # d(qkv) and d(t) of every block are kept until the block's group has run its batched weight-gradient products
+        # (L x 48.5 MB at B = 16: 1.9 GB of the 288)
+        w.dqkv_all = e(c.L if c.lora else 1, M, 3 * D)
         w.dsum = e(B, c.H, c.ntok, dt=torch.float32)
-        w.dt = e(M, 2 * c.rank) if c.lora else None
+        w.dt_all = e(c.L, M, 2 * c.rank) if c.lora else None
 
     # ------------------------------------------------------------------ forward
     def _drop_path_factors(self, w, c):
@@ -780,6 +787,7 @@ class HipEngine:
         r_ = c.rank
         scale = c.Dh ** -0.5
         lsplit = max(1, min(512 // ((D + 127) // 128), (M + 255) // 256))
+        G = max(1, int(self.lora_group))
         last = fz.blocks[c.L - 1]
         dp = getattr(w, "dpath", None)          # DropPath factors of the forward pass this backward belongs to
         rs = (lambda l, br: None) if dp is None else (lambda l, br: dp[l, br])
@@ -796,24 +804,32 @@ class HipEngine:
             ops.layernorm_bwd(w.dh, w.x_mid[l], b.n2w, w.dx, b.ls1, w.dy, c.eps, accumulate=True, rowscale_next=rs(l, 0))
             # attention branch: dy = ls1 * dx
             ops.gemm(w.dy, b.t.wproj, w.do)
-            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, w.dqkv, B, c.ntok, c.H, c.Dh, scale)
-            dq, dv = w.dqkv, w.dqkv.view(-1)[2 * D:]
+            dqkv, dt = w.dqkv_all[l], w.dt_all[l]
+            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, dqkv, B, c.ntok, c.H, c.Dh, scale)
+            dq, dv = dqkv, dqkv.view(-1)[2 * D:]
             # dt_q = dq @ (a B_q)^T, dt_v = dv @ (a B_v)^T: one launch
-            ops.skinny_xw2(dq, pk.Bq16[l], w.dt, dv, pk.Bv16[l], w.dt.view(-1)[r_:], ldx=3 * D, ldw=D, ldo=2 * r_, M=M, K=D, R=r_)
-            t = w.t[l]
-            # LoRA weight gradients on the TN MFMA GEMM, both adapters per pass: dB = t^T [dq | . | dv] (rows of B_q from
-            # the q columns, rows of B_v from the v columns), dA = ([dt_q | dt_v]^T h)^T (columns of A_q, A_v)
-            ops.gemm_tn(t, w.dqkv, fl.dBq[l], M=M, I=2 * r_, J=3 * D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1, msplit=lsplit,
-                        c2=fl.dBv[l], isplit=r_, j1=D, jlo2=2 * D)
-            ops.gemm_tn(w.dt, w.h1[l], fl.dAq[l], M=M, I=2 * r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_, msplit=lsplit,
-                        c2=fl.dAv[l], isplit=r_)
-            if c.alpha != 1.0:       # B2 carries alpha*B: d(B) = alpha * d(alpha*B); scaled before the slice may be exchanged
-                fl.dBq[l].mul_(c.alpha)
-                fl.dBv[l].mul_(c.alpha)
-            if on_block_done is not None:
-                on_block_done(l)
+            ops.skinny_xw2(dq, pk.Bq16[l], dt, dv, pk.Bv16[l], dt.view(-1)[r_:], ldx=3 * D, ldw=D, ldo=2 * r_, M=M, K=D, R=r_)
+            if l % G == 0:
+                # LoRA weight gradients of blocks l .. l+G-1 on the TN MFMA GEMM, both adapters per pass and the whole group
+                # per launch: dB = t^T [dq | . | dv] (rows of B_q from the q columns, rows of B_v from the v columns),
+                # dA = ([dt_q | dt_v]^T h)^T (columns of A_q, A_v).  One block's products are 4 steps of m per workgroup -
+                # latency-bound at 13 us each; a group of 10 streams its operands at the fabric rate.
+                n = min(G, c.L - l)
+                gsplit = max(1, min(lsplit, -(-1024 // (n * 2 * ((D + 127) // 128)))))
+                ops.gemm_tn(w.t[l], dqkv, fl.dBq[l], M=M, I=2 * r_, J=3 * D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1,
+                            msplit=gsplit, c2=fl.dBv[l], isplit=r_, j1=D, jlo2=2 * D, batch=n, stride_a=M * 2 * r_,
+                            stride_b=M * 3 * D, stride_c=4 * r_ * D)
+                ops.gemm_tn(dt, w.h1[l], fl.dAq[l], M=M, I=2 * r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_,
+                            msplit=max(1, min(lsplit, 2 * gsplit)), c2=fl.dAv[l], isplit=r_, batch=n, stride_a=M * 2 * r_,
+                            stride_b=M * D, stride_c=4 * r_ * D)
+                for j in range(l + n - 1, l - 1, -1):
+                    if c.alpha != 1.0:   # B2 carries alpha*B: d(B) = alpha * d(alpha*B); scaled before the slice may be exchanged
+                        fl.dBq[j].mul_(c.alpha)
+                        fl.dBv[j].mul_(c.alpha)
+                    if on_block_done is not None:
+                        on_block_done(j)
             if l > 0:
-                ops.gemm(w.dqkv, b.t.wqkv, w.dh, a2=w.dt, b2=pk.Acat16[l], K2=2 * r_)
+                ops.gemm(dqkv, b.t.wqkv, w.dh, a2=dt, b2=pk.Acat16[l], K2=2 * r_)
                 if inject is not None:
                     inject(l - 1)
                 ops.layernorm_bwd(w.dh, w.x_in[l], b.n1w, w.dx, fz.blocks[l - 1].ls2, w.dy, c.eps, accumulate=True,

@@ -103,13 +103,15 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
 
 
 def gemm_tn(a, b, c, *, M, I, J, lda=None, ldb=None, ldci=None, ldcj=1, msplit=1, conv=None, c2=None, isplit=0, j1=0,
-            jlo2=0):
+            jlo2=0, batch=1, stride_a=0, stride_b=0, stride_c=0):
     """C[i,j] (f32, += ) = sum_m A[m,i] * B[m,j]; conv=(H, W, C, ld, OH, OW, stride) makes A the virtual im2col.
-    c2/isplit(/j1/jlo2): second output from the same pass (rows >= isplit, optionally columns >= jlo2), see the header."""
+    c2/isplit(/j1/jlo2): second output from the same pass (rows >= isplit, optionally columns >= jlo2), see the header.
+    batch > 1: that many independent products from one launch, operand / output b at base + b * stride (elements)."""
     _chk_bf16(a, "A")
     _chk_bf16(b, "B")
     assert c.dtype == torch.float32
     g = L.GemmTnArgs()
+    g.batch, g.strideA, g.strideB, g.strideC = batch, stride_a, stride_b, stride_c
     g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
     g.M, g.I, g.J = M, I, J
     g.ldb = ldb if ldb is not None else b.stride(0)
