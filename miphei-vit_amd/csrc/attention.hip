@@ -56,34 +56,44 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const bf16_t* ptr) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rsrc, char* tile, int row0, int nvalid, int Dh,
-                                         unsigned rs, int tid) {
-  typedef __attribute__((address_space(3))) void* lds_ptr;
+// This lane's two 16-byte pieces of a 64-row tile as byte offsets from the tile's first row: tile constants, the tile advance
+// rides on the scalar offset of the DMA, so issuing a tile costs no address arithmetic (only the ragged last tile re-checks rows).
+struct TileOff { unsigned full[2]; };
+__device__ __forceinline__ TileOff tile_offsets(int Dh, unsigned rs, int tid) {
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  TileOff o;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = 8 * wave_u + 32 * j + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    unsigned off = (row0 + row < nvalid && c * 8 < Dh) ? ((unsigned)(row0 + row) * rs + (unsigned)c * 8u) * 2u : 0x80000000u;
-    asm volatile("" : "+v"(off));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(tile + (8 * wave_u + 32 * j) * 128), 16, off, 0, 0, 0);
+    o.full[j] = c * 8 < Dh ? ((unsigned)row * rs + (unsigned)c * 8u) * 2u : 0x80000000u;
+  }
+  return o;
+}
+__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, const TileOff& o, int row0, int nvalid, unsigned rs,
+                                         int tid) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int soff = row0 * (int)rs * 2;
+  unsigned off[2] = {o.full[0], o.full[1]};
+  if (row0 + KVB > nvalid) {  // uniform: the ragged last tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (row0 + 8 * wave_u + 32 * j + (lane >> 3) >= nvalid) off[j] = 0x80000000u;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    asm volatile("" : "+v"(off[j]));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(tile + (8 * wave_u + 32 * j) * 128), 16, off[j], soff, 0, 0);
   }
 }
 
-// 4-deep ring of [K|V] (or [Q|dO]) tile pairs: up to 3 tiles of DMA stay in flight, so after the first tile the
-// loop never waits on memory latency.  Counted vmcnt (4 DMA instructions per thread per tile pair) + raw s_barrier.
-constexpr int NRING = 2;      // dkv kernel
-constexpr int NRING_Q = 2;    // query-stationary kernels (fwd, dq): smaller LDS footprint -> more blocks per CU
+// Two-slot ring of [K|V] (or [Q|dO]) tile pairs: the DMA of tile t+1 is issued behind the barrier of step t and waited for at the
+// top of step t+1.  The tile loop is unrolled by two so that the slot of a step is a compile-time constant (every LDS address of
+// the step is then lane constant + immediate).  (Deeper rings: 48 KB per block costs the third resident block per CU.)
+constexpr int NRING = 2;
+constexpr int NRING_Q = 2;
 constexpr float RESCALE_THR = 6.f;  // log2 units
-__device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
-  if (ahead >= 2)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (ahead == 1)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   union { uint32_t u[4]; bf16x8 v; } r;
 #pragma unroll
@@ -139,22 +149,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
 
   const int ntiles = (N + KVB - 1) / KVB;
   const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
-  auto issue = [&](int t) {
-    char* dst = smem + (t & (NRING_Q - 1)) * 2 * TILE_BYTES;
-    dma_rows(rK, dst, t * KVB, N, Dh, (unsigned)rs, tid);
-    dma_rows(rV, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)rs, tid);
+  const TileOff to = tile_offsets(Dh, (unsigned)rs, tid);
+  auto issue = [&](int t, char* dst) {
+    dma_tile(rK, dst, to, t * KVB, N, (unsigned)rs, tid);
+    dma_tile(rV, dst + TILE_BYTES, to, t * KVB, N, (unsigned)rs, tid);
   };
-  for (int t = 0; t < NRING_Q - 1 && t < ntiles; ++t) issue(t);
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & (NRING_Q - 1);
-    wait_tiles_in_flight(min(NRING_Q - 2, ntiles - 1 - t));
-    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (ring slot of t+3)
-    if (t + NRING_Q - 1 < ntiles) issue(t + NRING_Q - 1);
-    const char* Ks = smem + cur * 2 * TILE_BYTES;
+  issue(0, smem);
+  auto step = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
+    if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
+    const char* Ks = smem + SLOT * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
 
-    if (q0 >= N) continue;  // wave-uniform: this wave's 32 query rows are all padding
+    if (q0 >= N) return;  // wave-uniform: this wave's 32 query rows are all padding
     auto tile_body = [&](auto ragged_tag) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
       const bool kt1_live = !RAGGED || kv0 + 32 < N;  // second 32-key half of the tile holds at least one real key
@@ -231,6 +241,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
       tile_body(std::true_type{});
     else
       tile_body(std::false_type{});
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(t, std::integral_constant<int, 0>{});
+    if (t + 1 < ntiles) step(t + 1, std::integral_constant<int, 1>{});
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
@@ -306,21 +320,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
 
   const int ntiles = (N + KVB - 1) / KVB;
   const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
-  auto issue = [&](int t) {
-    char* dst = smem + (t & (NRING_Q - 1)) * 2 * TILE_BYTES;
-    dma_rows(rK, dst, t * KVB, N, Dh, (unsigned)rs, tid);
-    dma_rows(rV, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)rs, tid);
+  const TileOff to = tile_offsets(Dh, (unsigned)rs, tid);
+  auto issue = [&](int t, char* dst) {
+    dma_tile(rK, dst, to, t * KVB, N, (unsigned)rs, tid);
+    dma_tile(rV, dst + TILE_BYTES, to, t * KVB, N, (unsigned)rs, tid);
   };
-  for (int t = 0; t < NRING_Q - 1 && t < ntiles; ++t) issue(t);
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & (NRING_Q - 1);
-    wait_tiles_in_flight(min(NRING_Q - 2, ntiles - 1 - t));
-    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (ring slot of t+3)
-    if (t + NRING_Q - 1 < ntiles) issue(t + NRING_Q - 1);
-    const char* Ks = smem + cur * 2 * TILE_BYTES;
+  issue(0, smem);
+  auto step = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+    const int SLOT = slot_tag;   // (a compile-time slot - loop unrolled by two - costs registers here: spills at the occupancy cap)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
+    if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
+    const char* Ks = smem + SLOT * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
-    if (bxy.x * 128 + wave * 32 >= N) continue;  // dead wave (padding rows only)
+    if (bxy.x * 128 + wave * 32 >= N) return;  // dead wave (padding rows only)
     auto tile_body = [&](auto ragged_tag) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
       const bool kt1_live = !RAGGED || kv0 + 32 < N;
@@ -364,7 +378,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
       tile_body(std::true_type{});
     else
       tile_body(std::false_type{});
-  }
+  };
+  for (int t = 0; t < ntiles; ++t) step(t, t & 1);
   if (q < N) {
     bf16_t* orow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * Dh;
 #pragma unroll
@@ -423,27 +438,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
   const __amdgpu_buffer_rsrc_t rQ = make_rsrc(qb), rD = make_rsrc(dob);
   const int ntiles = (N + KVB - 1) / KVB;
-  auto issue = [&](int t) {
-    char* dst = smem + (t & (NRING - 1)) * 2 * TILE_BYTES;
-    dma_rows(rQ, dst, t * KVB, N, Dh, (unsigned)rs, tid);
-    dma_rows(rD, dst + TILE_BYTES, t * KVB, N, Dh, (unsigned)ors, tid);
+  const TileOff toq = tile_offsets(Dh, (unsigned)rs, tid), tod = tile_offsets(Dh, (unsigned)ors, tid);
+  auto issue = [&](int t, char* dst) {
+    dma_tile(rQ, dst, toq, t * KVB, N, (unsigned)rs, tid);
+    dma_tile(rD, dst + TILE_BYTES, tod, t * KVB, N, (unsigned)ors, tid);
   };
-  for (int t = 0; t < NRING - 1 && t < ntiles; ++t) issue(t);
+  issue(0, smem);
   for (int i = tid; i < Npad; i += 256) {  // per-row log-sum-exp and dO.O of the whole head (published by the first barrier)
     LD[i] = i < N ? lse[(size_t)bh * N + i] * LOG2E : 0.f;
     LD[Npad + i] = i < N ? Dv[(size_t)bh * N + i] : 0.f;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & (NRING - 1);
-    wait_tiles_in_flight(min(NRING - 2, ntiles - 1 - t));
+  auto step = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+    const int SLOT = slot_tag;   // (a compile-time slot - loop unrolled by two - costs registers here: spills at the occupancy cap)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + NRING - 1 < ntiles) issue(t + NRING - 1);
-    const char* Qs = smem + cur * 2 * TILE_BYTES;
+    if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
+    const char* Qs = smem + SLOT * 2 * TILE_BYTES;
     const char* Ds = Qs + TILE_BYTES;
     const int qt0 = t * KVB;
     const float* Ls = LD + qt0;
-    if (bxy.x * 128 + wave * 32 >= N) continue;  // dead wave (padding keys only)
+    if (bxy.x * 128 + wave * 32 >= N) return;  // dead wave (padding keys only)
     auto tile_body = [&](auto ragged_tag) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
       const bool qt1_live = !RAGGED || qt0 + 32 < N;
@@ -496,7 +511,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
       tile_body(std::true_type{});
     else
       tile_body(std::false_type{});
-  }
+  };
+  for (int t = 0; t < ntiles; ++t) step(t, t & 1);
   if (key < N) {
     bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)(dm.H + h) * Dh;
     bf16_t* vrow = krow + (size_t)dm.H * Dh;

@@ -24,6 +24,8 @@ f = t(lambda: ops.attention_fwd(qkv, out, lse, B, N, H, Dh, sc))
 b = t(lambda: ops.attention_bwd(qkv, out, dO, lse, dsum, dqkv, B, N, H, Dh, sc))
 fl = 4.0 * B * H * N * N * Dh
 print(f"N={N} fwd {f*1e3:.1f} us ({fl/f/1e9:.1f} TF/s)   bwd {b*1e3:.1f} us ({2.5*fl/b/1e9:.1f} TF/s useful)")
+if len(sys.argv) > 2 and sys.argv[2] == "ours":
+    sys.exit(0)
 # yardstick: the vendor attention behind torch SDPA (CK / AOTriton flash attention) on the same problem
 import torch.nn.functional as F
 q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).contiguous().requires_grad_(True) for i in range(3))   # [B, H, N, Dh]
