@@ -17,6 +17,7 @@
 namespace {
 
 typedef short v4s __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int KVB = 64;          // keys per LDS tile
@@ -155,8 +156,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     dma_tile(rV, dst + TILE_BYTES, to, t * KVB, N, (unsigned)rs, tid);
   };
   issue(0, smem);
-  auto step = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+  // `live`: this wave owns at least one real query row (padding-only waves still take part in the barriers and the DMA)
+  auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
@@ -164,9 +167,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
 
-    if (q0 >= N) return;  // wave-uniform: this wave's 32 query rows are all padding
-    auto tile_body = [&](auto ragged_tag) {
-      constexpr bool RAGGED = decltype(ragged_tag)::value;
+    if constexpr (!decltype(live_tag)::value) return;
+    {
       const bool kt1_live = !RAGGED || kv0 + 32 < N;  // second 32-key half of the tile holds at least one real key
     f32x16 st[2];
 #pragma unroll
@@ -209,16 +211,20 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
-    float lsum = 0.f;
+    // (packed f32 FMA / add: two scores per VALU instruction; the exponentials stay scalar)
+    const f32x2 sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
+    f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sc, -m_run));
-        st[kt][r] = p;
-        lsum += p;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = __builtin_elementwise_fma((f32x2){st[kt][r], st[kt][r + 1]}, sc2, nm2);
+        const f32x2 p2 = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+        st[kt][r] = p2.x;
+        st[kt][r + 1] = p2.y;
+        ls2 += p2;
       }
-    l_run += lsum;
+    l_run += ls2.x + ls2.y;
     // O^T += V^T P^T
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
@@ -236,16 +242,30 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[dt], 0, 0, 0);
       }
     }
-      };
-    if (kv0 + KVB > N)
-      tile_body(std::true_type{});
-    else
-      tile_body(std::false_type{});
+    }
   };
-  for (int t = 0; t < ntiles; t += 2) {
-    step(t, std::integral_constant<int, 0>{});
-    if (t + 1 < ntiles) step(t + 1, std::integral_constant<int, 1>{});
-  }
+  // full tiles two at a time (compile-time ring slot), then the odd full tile, then the ragged last tile: one straight-line body
+  // per loop, so the accumulators never move between registers
+  auto run = [&](auto live_tag) __attribute__((always_inline)) {
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nfull = N / KVB;
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+      step(t, S0{}, std::false_type{}, live_tag);
+      step(t + 1, S1{}, std::false_type{}, live_tag);
+    }
+    if (t < nfull) {
+      step(t, S0{}, std::false_type{}, live_tag);
+      if (t + 1 < ntiles) step(t + 1, S1{}, std::true_type{}, live_tag);
+    } else if (t < ntiles) {
+      step(t, S0{}, std::true_type{}, live_tag);
+    }
+  };
+  if (q0 >= N)  // wave-uniform
+    run(std::false_type{});
+  else
+    run(std::true_type{});
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   if (q < N) {
