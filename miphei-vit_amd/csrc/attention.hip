@@ -346,17 +346,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     dma_tile(rV, dst + TILE_BYTES, to, t * KVB, N, (unsigned)rs, tid);
   };
   issue(0, smem);
-  auto step = [&](int t, auto slot_tag) __attribute__((always_inline)) {
-    const int SLOT = slot_tag;   // (a compile-time slot - loop unrolled by two - costs registers here: spills at the occupancy cap)
+  auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
     const char* Ks = smem + SLOT * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
     const int kv0 = t * KVB;
-    if (bxy.x * 128 + wave * 32 >= N) return;  // dead wave (padding rows only)
-    auto tile_body = [&](auto ragged_tag) {
-      constexpr bool RAGGED = decltype(ragged_tag)::value;
+    if constexpr (!decltype(live_tag)::value) return;
+    {
       const bool kt1_live = !RAGGED || kv0 + 32 < N;
       // one 32-key sub-tile at a time: S^T, dP^T -> dS^T -> dQ^T
 #pragma unroll
@@ -393,13 +393,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
           }
         }
       }
-      };
-    if (kv0 + KVB > N)
-      tile_body(std::true_type{});
-    else
-      tile_body(std::false_type{});
+    }
   };
-  for (int t = 0; t < ntiles; ++t) step(t, t & 1);
+  auto run = [&](auto live_tag) __attribute__((always_inline)) {   // (see the forward kernel)
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nfull = N / KVB;
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+      step(t, S0{}, std::false_type{}, live_tag);
+      step(t + 1, S1{}, std::false_type{}, live_tag);
+    }
+    if (t < nfull) {
+      step(t, S0{}, std::false_type{}, live_tag);
+      if (t + 1 < ntiles) step(t + 1, S1{}, std::true_type{}, live_tag);
+    } else if (t < ntiles) {
+      step(t, S0{}, std::true_type{}, live_tag);
+    }
+  };
+  if (bxy.x * 128 + wave * 32 >= N)  // wave-uniform: padding rows only
+    run(std::false_type{});
+  else
+    run(std::true_type{});
   if (q < N) {
     bf16_t* orow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * Dh;
 #pragma unroll
@@ -469,8 +484,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     LD[Npad + i] = i < N ? Dv[(size_t)bh * N + i] : 0.f;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  auto step = [&](int t, auto slot_tag) __attribute__((always_inline)) {
-    const int SLOT = slot_tag;   // (a compile-time slot - loop unrolled by two - costs registers here: spills at the occupancy cap)
+  auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
@@ -478,9 +494,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const char* Ds = Qs + TILE_BYTES;
     const int qt0 = t * KVB;
     const float* Ls = LD + qt0;
-    if (bxy.x * 128 + wave * 32 >= N) return;  // dead wave (padding keys only)
-    auto tile_body = [&](auto ragged_tag) {
-      constexpr bool RAGGED = decltype(ragged_tag)::value;
+    if constexpr (!decltype(live_tag)::value) return;
+    {
       const bool qt1_live = !RAGGED || qt0 + 32 < N;
       // one 32-row query sub-tile at a time: S, dP -> P, dS -> dV^T, dK^T (keeps the live accumulator set small)
 #pragma unroll
@@ -526,13 +541,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
           }
         }
       }
-      };
-    if (qt0 + KVB > N)
-      tile_body(std::true_type{});
-    else
-      tile_body(std::false_type{});
+    }
   };
-  for (int t = 0; t < ntiles; ++t) step(t, t & 1);
+  auto run = [&](auto live_tag) __attribute__((always_inline)) {   // (see the forward kernel)
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nfull = N / KVB;
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+      step(t, S0{}, std::false_type{}, live_tag);
+      step(t + 1, S1{}, std::false_type{}, live_tag);
+    }
+    if (t < nfull) {
+      step(t, S0{}, std::false_type{}, live_tag);
+      if (t + 1 < ntiles) step(t + 1, S1{}, std::true_type{}, live_tag);
+    } else if (t < ntiles) {
+      step(t, S0{}, std::true_type{}, live_tag);
+    }
+  };
+  if (bxy.x * 128 + wave * 32 >= N)  // wave-uniform: padding rows only
+    run(std::false_type{});
+  else
+    run(std::true_type{});
   if (key < N) {
     bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)(dm.H + h) * Dh;
     bf16_t* vrow = krow + (size_t)dm.H * Dh;
