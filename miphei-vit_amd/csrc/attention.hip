@@ -372,11 +372,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
           const bf16x8 v = *(const bf16x8*)(Vs + swz(32 * kt + l31, 2 * s + half));
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, dof[s], dp, 0, 0, 0);
         }
+        // dS^T = P (dP - D) scale, two scores per packed VALU instruction
+        const f32x2 sc2 = {sc, sc}, nL2 = {-Lq, -Lq}, s2 = {dm.scale, dm.scale}, nD2 = {-Dq * dm.scale, -Dq * dm.scale};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 16; r += 2) {
           const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float p = (!RAGGED || key < N) ? __builtin_amdgcn_exp2f(fmaf(st[r], sc, -Lq)) : 0.f;
-          st[r] = p * (dp[r] - Dq) * dm.scale;  // dS^T
+          const f32x2 x = __builtin_elementwise_fma((f32x2){st[r], st[r + 1]}, sc2, nL2);
+          f32x2 p2 = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+          if (RAGGED) p2 = {key < N ? p2.x : 0.f, key + 1 < N ? p2.y : 0.f};
+          const f32x2 ds2 = p2 * __builtin_elementwise_fma((f32x2){dp[r], dp[r + 1]}, s2, nD2);
+          st[r] = ds2.x;
+          st[r + 1] = ds2.y;
         }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   issue(0, smem);
   for (int i = tid; i < Npad; i += 256) {  // per-row log-sum-exp and dO.O of the whole head (published by the first barrier)
     LD[i] = i < N ? lse[(size_t)bh * N + i] * LOG2E : 0.f;
-    LD[Npad + i] = i < N ? Dv[(size_t)bh * N + i] : 0.f;
+    LD[Npad + i] = i < N ? Dv[(size_t)bh * N + i] * dm.scale : 0.f;   // D pre-multiplied by the softmax scale
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
@@ -517,11 +523,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
           const float4 L4 = *(const float4*)(Ls + qb4), D4 = *(const float4*)(Ls + Npad + qb4);
           const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv_[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < 4; e += 2) {   // two query rows per packed VALU instruction
             const int r = 4 * g + e;
-            const float p = (!RAGGED || qt0 + qb4 + e < N) ? __builtin_amdgcn_exp2f(fmaf(st[r], sc, -Lv[e])) : 0.f;
-            st[r] = p;                                  // P
-            dp[r] = p * (dp[r] - Dv_[e]) * dm.scale;   // dS
+            const f32x2 x = __builtin_elementwise_fma((f32x2){st[r], st[r + 1]}, (f32x2){sc, sc}, (f32x2){-Lv[e], -Lv[e + 1]});
+            f32x2 p2 = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            if (RAGGED) p2 = {qt0 + qb4 + e < N ? p2.x : 0.f, qt0 + qb4 + e + 1 < N ? p2.y : 0.f};
+            const f32x2 ds2 = p2 * __builtin_elementwise_fma((f32x2){dp[r], dp[r + 1]}, (f32x2){dm.scale, dm.scale},
+                                                              (f32x2){-Dv_[e], -Dv_[e + 1]});   // (D is stored scaled)
+            st[r] = p2.x, st[r + 1] = p2.y;        // P
+            dp[r] = ds2.x, dp[r + 1] = ds2.y;      // dS
           }
         }
 #pragma unroll
