@@ -60,3 +60,34 @@ def test_training_steps_match_reference(golden_dir, name):
             d_got = named[k].detach().cpu() - p[k]
             if float(d_ref.norm()) > 0:
                 assert _rel(d_got, d_ref) < 0.35, k  # Adam normalises gradients: bf16 noise shows up in tiny moves
+
+
+def test_lora_group_size_does_not_change_gradients():
+    """The LoRA weight-gradient products run batched over groups of ViT blocks (HipEngine.lora_group); any grouping - one block per
+    launch, a partial group, all blocks - must give the same LoRA gradients."""
+    from oracle import VIT_CONFIGS, det_state_dict, synth_batch
+    from oracle.model import generator_state_shapes, orion_marker_weights
+    from miphei_vit_amd.generators import get_vitmatte
+    from miphei_vit_amd.loss import WeightedMSELoss
+    from miphei_vit_amd.models import ModelModule
+    cfgname, img, nc, B = "tiny4_swiglu", 128, 3, 2
+    sd = det_state_dict(generator_state_shapes(VIT_CONFIGS[cfgname], img, nc), seed=5, layerscale=0.5)
+    p = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    x, y = synth_batch(77, B, img, nc)
+    grads = []
+    for group in (1, 1, 3, 10):
+        model = get_vitmatte(cfgname, img, nc, use_lora=True, pretrained=False)
+        model.load_state_dict(p)
+        model.cuda()
+        model._engine.lora_group = group
+        mod = ModelModule(model, None, 1e-4, 0., WeightedMSELoss(50.0, orion_marker_weights(nc)))
+        mod.total_iters = 100
+        mod.training_step({"image": x.cuda(), "target": y.cuda()}, 0)
+        c = model._engine._config()
+        grads.append(model._engine._flat.gflat[:c.L * 4 * c.rank * c.D].clone())     # the LoRA region of the flat gradient
+    assert float(grads[0].abs().max()) > 0
+    # two runs of the SAME grouping differ (f32 atomics upstream flip bf16 roundings): that is the yardstick; a wrong stride is O(1)
+    noise = _rel(grads[1], grads[0])
+    assert noise < 0.05
+    for g in grads[2:]:
+        assert _rel(g, grads[0]) < max(3 * noise, 1e-3)
