@@ -67,6 +67,24 @@ def test_skinny():
     assert _rel(out3[:, 8:].float(), Xw[:, 208:].float() @ Bm.float().t()) < 4e-3
 
 
+@pytest.mark.parametrize("K,R,M", [(1536, 8, 5264), (512, 5, 333), (1024, 8, 1000), (2048, 8, 70)])
+def test_skinny_rows(K, R, M):
+    """the encoder's dt = dq B_q^T || dv B_v^T shapes (column windows of the packed d(qkv)), single and paired launch"""
+    ops = _ops()
+    Xw = _rand(M, 3 * K, seed=1).bfloat16()
+    Wq = _rand(R, K, seed=2, scale=0.1).bfloat16()
+    Wv = _rand(R, K, seed=3, scale=0.1).bfloat16()
+    out = torch.full((M, 16), 9.0, device="cuda", dtype=torch.bfloat16)
+    ops.skinny_xw2(Xw, Wq, out, Xw.view(-1)[2 * K:], Wv, out.view(-1)[8:], ldx=3 * K, ldw=K, ldo=16, M=M, K=K, R=R)
+    assert _rel(out[:, :R].float(), Xw[:, :K].float() @ Wq.float().t()) < 4e-3
+    assert _rel(out[:, 8:8 + R].float(), Xw[:, 2 * K:].float() @ Wv.float().t()) < 4e-3
+    if R < 8:   # columns past R are not written
+        assert float((out[:, R:8].float() - 9.0).abs().max()) == 0
+    one = torch.empty(M, R, device="cuda", dtype=torch.bfloat16)
+    ops.skinny_xw(Xw.view(-1)[K:], Wq, one, ldx=3 * K, M=M)
+    assert _rel(one.float(), Xw[:, K:2 * K].float() @ Wq.float().t()) < 4e-3
+
+
 def test_patch_prefix_cast():
     ops = _ops()
     B, S, p = 2, 128, 14

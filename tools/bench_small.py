@@ -32,6 +32,9 @@ A = torch.randn(16, D, device="cuda").to(bf)
 t = torch.empty(M, 16, device="cuda", dtype=bf)
 print(f"ln_fwd                 {timeit(lambda: ops.layernorm_fwd(x, w, b, h)):7.1f} us")
 print(f"skinny_xw (t = h A)    {timeit(lambda: ops.skinny_xw(h, A, t)):7.1f} us")
+dqkv = torch.randn(M, 3 * D, device="cuda").to(bf)
+Bq, Bv = torch.randn(8, D, device="cuda").to(bf), torch.randn(8, D, device="cuda").to(bf)
+print(f"skinny_xw2 (dt, R = 8) {timeit(lambda: ops.skinny_xw2(dqkv, Bq, t, dqkv.view(-1)[2 * D:], Bv, t.view(-1)[8:], ldx=3 * D, ldw=D, ldo=16, M=M, K=D, R=8)):7.1f} us")
 print(f"ln_fwd + lora fused    {timeit(lambda: ops.layernorm_lora_fwd(x, w, b, h, A, t)):7.1f} us", flush=True)
 
 B, S, cin, cp, cout = 16, 256, 67, 72, 32
