@@ -92,6 +92,13 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
     const long long pix = i % ((long long)S * S);
     const int b = (int)(i / ((long long)S * S));
     bf16_t* o = dst + (size_t)i * ld_dst;
+    if (C + nzero == 8 && (ld_dst & 7) == 0 && ((uintptr_t)dst & 15) == 0) {   // the 8-channel image buffer: one 16-byte store per pixel
+      float f[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) f[c] = c < C ? img[((size_t)b * C + c) * S * S + pix] : 0.f;
+      *(uint4*)o = pack8f(f);
+      continue;
+    }
     for (int c = 0; c < C; ++c) o[c] = f2bf(img[((size_t)b * C + c) * S * S + pix]);
     for (int c = 0; c < nzero; ++c) o[C + c] = 0;
   }
@@ -99,23 +106,34 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
 
 // ------------------------------------------------------------------ BatchNorm: statistics -> scale / shift
 // stats: [nslots][2][C] doubles (sum, sum of squares) accumulated by the conv epilogue.
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+// 32 lanes per channel: lane k sums slots k, k + 32, ... and the partial sums meet through a shuffle tree (one load latency
+// instead of nslots dependent ones: 13 -> 4 us for a kernel that runs 7 times per step).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
                                    float* __restrict__ rstd_o, int C, int nslots, double count, float eps, float momentum,
                                    int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double mean, var;
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), k0 = threadIdx.x & 31;
+  const bool ok = c < C;
+  double mean = 0., var = 0.;
   if (training) {
     double s = 0., q = 0.;
-    for (int k = 0; k < nslots; ++k) {
-      s += stats[(size_t)k * 2 * C + c];
-      q += stats[(size_t)k * 2 * C + C + c];
+    if (ok)
+      for (int k = k0; k < nslots; k += 32) {
+        s += stats[(size_t)k * 2 * C + c];
+        q += stats[(size_t)k * 2 * C + C + c];
+      }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+      s += __shfl_xor(s, d, 32);
+      q += __shfl_xor(q, d, 32);
     }
     mean = s / count;
     var = q / count - mean * mean;
     if (var < 0.) var = 0.;
+  }
+  if (!ok || k0 != 0) return;
+  if (training) {
     const double unb = count > 1. ? var * count / (count - 1.) : var;
     rmean[c] = (float)((1. - momentum) * rmean[c] + momentum * mean);
     rvar[c] = (float)((1. - momentum) * rvar[c] + momentum * unb);
@@ -378,7 +396,7 @@ MVIT_API int mvit_bn_finalize(const double* stats, const float* gamma, const flo
                               int nslots, double count, float eps, float momentum, int training, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (C <= 0 || (training && (!stats || nslots <= 0 || count <= 0))) return MVIT_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta,
                      running_mean, running_var, scale, shift, mean_out, rstd_out, C, nslots, count, eps, momentum, training);
   return MVIT_LAUNCH_CHECK();
 }

@@ -191,7 +191,6 @@ __global__ __launch_bounds__(1024) void bn_from_moments_kernel(const double* __r
                                                                int training) {
   __shared__ double ms[NMOM];
   __shared__ double cov[XC * XC];
-  const int ch = threadIdx.x;
   if (training) {
     for (int e = threadIdx.x; e < NMOM; e += 1024) {
       double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
@@ -214,35 +213,47 @@ __global__ __launch_bounds__(1024) void bn_from_moments_kernel(const double* __r
     }
     __syncthreads();
   }
-  if (ch >= NCH) return;
-  double mean, var;
+  static_assert(MAXH * HC * 4 <= 1024, "four lanes per gate channel in one block");
+  // four lanes per channel: lane q takes rows q, q + 4, ... of the quadratic form w^T cov w (all 1024 threads work)
+  const int ch4 = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+  double mean = 0., var = 0.;
   if (training) {
-    const float* w = W1 + (size_t)ch * XC;
-    double wm = 0.;
-    for (int k = 0; k < XC; ++k) wm += (double)w[k] * ms[k] / count;
-    mean = wm + b1[ch];
-    double v = 0.;
+    const bool ok = ch4 < NCH;
+    const float* w = W1 + (size_t)(ok ? ch4 : 0) * XC;
+    double wd[XC];
+#pragma unroll
+    for (int k = 0; k < XC; ++k) wd[k] = (double)w[k];
+    double wm = 0., v = 0.;
 #pragma unroll 1
-    for (int j = 0; j < XC; ++j) {
+    for (int j = q4; j < XC; j += 4) {
+      wm += wd[j] * ms[j];
       double row = 0.;
-#pragma unroll 4
-      for (int k = 0; k < XC; ++k) row += (double)w[k] * cov[j * XC + k];
-      v += (double)w[j] * row;
+#pragma unroll
+      for (int k = 0; k < XC; ++k) row += wd[k] * cov[j * XC + k];
+      v += wd[j] * row;
     }
+    wm += __shfl_xor(wm, 1, 64), v += __shfl_xor(v, 1, 64);
+    wm += __shfl_xor(wm, 2, 64), v += __shfl_xor(v, 2, 64);
+    mean = wm / count + (ok ? b1[ch4] : 0.f);
     var = v < 0. ? 0. : v;
+  }
+  // (channel ch4 is finished by its lane 0; the statements below keep the one-thread-per-channel form)
+  if (ch4 >= NCH || q4 != 0) return;
+  const int chn = ch4;
+  if (training) {
     const double unb = count > 1. ? var * count / (count - 1.) : var;
-    rmean[ch] = (float)((1. - momentum) * rmean[ch] + momentum * mean);
-    rvar[ch] = (float)((1. - momentum) * rvar[ch] + momentum * unb);
+    rmean[chn] = (float)((1. - momentum) * rmean[chn] + momentum * mean);
+    rvar[chn] = (float)((1. - momentum) * rvar[chn] + momentum * unb);
   } else {
-    mean = rmean[ch];
-    var = rvar[ch];
+    mean = rmean[chn];
+    var = rvar[chn];
   }
   const double rstd = 1. / sqrt(var + (double)eps);
-  const double sc = gamma[ch] * rstd;
-  scale[ch] = (float)sc;
-  shift[ch] = (float)(beta[ch] - mean * sc);
-  if (mean_o) mean_o[ch] = (float)mean;
-  if (rstd_o) rstd_o[ch] = (float)rstd;
+  const double sc = gamma[chn] * rstd;
+  scale[chn] = (float)sc;
+  shift[chn] = (float)(beta[chn] - mean * sc);
+  if (mean_o) mean_o[chn] = (float)mean;
+  if (rstd_o) rstd_o[chn] = (float)rstd;
 }
 
 // ------------------------------------------------------------------ gate forward
