@@ -153,6 +153,18 @@ MVIT_API int mvit_resample2d(const void* src, void* dst, const int* ty_idx, cons
                              const float* tx_w, const float* scale, const float* shift, int B, int h, int w, int H, int W,
                              int C, int ld_src, int ld_dst, long long src_bstride, long long dst_bstride, int T,
                              mvit_stream_t stream);
+/* The x2 bilinear case of the above (F.interpolate(scale_factor=2, mode="bilinear", align_corners=False), Fusion_Block.forward,
+ * src/generators/mipheivit.py:89) without tap tables: dst[b, 0:2h, 0:2w, 0:C] from src[b, 0:h, 0:w, 0:C], the producer's
+ * BatchNorm+ReLU (scale/shift, both or neither) applied to every source value.  extra8 (optional): NHWC bf16 [B, 2h, 2w, 8],
+ * copied into channels [C, C+8) of dst - the image slice D0 of the last concat buffer (Detail_Capture.forward,
+ * mipheivit.py:208-211).  C, ld_src, ld_dst multiples of 8; *_bstride in elements. */
+MVIT_API int mvit_upsample2x_bilinear(const void* src, void* dst, const float* scale, const float* shift, const void* extra8,
+                                      int B, int h, int w, int C, int ld_src, int ld_dst, long long src_bstride,
+                                      long long dst_bstride, mvit_stream_t stream);
+/* Backward of mvit_upsample2x_bilinear w.r.t. its (post-activation) input: d_in[b, 0:h, 0:w, 0:C] (bf16) from
+ * d_out[b, 0:2h, 0:2w, 0:C] (bf16, a channel slice of the concat gradient) - the adjoint of the interpolation matrix. */
+MVIT_API int mvit_upsample2x_bilinear_bwd(const void* d_out, void* d_in, int B, int h, int w, int C, int ld_dout, int ld_din,
+                                          long long dout_bstride, long long din_bstride, mvit_stream_t stream);
 /* NCHW f32 image -> channels [0,C) of an NHWC bf16 buffer with pixel stride ld_dst; nzero trailing channels cleared
  * (D0 skip of Detail_Capture.forward, mipheivit.py:208-211, and the ConvStream input). */
 MVIT_API int mvit_image_to_nhwc(const float* img, void* dst, int B, int S, int C, int ld_dst, int nzero,

@@ -63,6 +63,8 @@ SIGNATURES = {
     "mvit_attention_fwd": [vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_attention_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_resample2d": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ll, ll, ci, vp],
+    "mvit_upsample2x_bilinear": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ll, ll, vp],
+    "mvit_upsample2x_bilinear_bwd": [vp, vp, ci, ci, ci, ci, ci, ci, ll, ll, vp],
     "mvit_image_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_bn_finalize": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cf, cf, ci, vp],
     "mvit_bn_relu_apply": [vp, vp, vp, vp, ll, ci, ci, ci, cf, C.c_ulonglong, vp],

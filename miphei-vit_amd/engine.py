@@ -550,8 +550,7 @@ class HipEngine:
         ops.resample2d(w.tok[c.prefix:], w.feat, ty, ty, B=B, h=c.grid, w=c.grid, H=G, W=G, C=D, ld_src=D, ld_dst=D,
                        src_bstride=c.ntok * D, dst_bstride=G * G * D)
         ops.image_to_nhwc(x, w.img8, 8, nzero=5)
-        ld3 = w.cat[3].shape[-1]
-        ops.image_to_nhwc(x, w.cat[3].view(-1)[FUS_OUT[2]:], ld3, nzero=0)
+        # (the image slice of the last concat buffer is copied from img8 by the up-sampling kernel that fills the rest of it)
         # ConvStream: conv3x3 s2 -> BN -> ReLU, written into the skip slice of the matching concat buffer
         src = [(w.img8, S, 8, 8), (w.cat[2], s1, 48, w.cat[2].shape[-1]), (w.cat[1], s2, 96, w.cat[1].shape[-1])]
         dst = [(w.cat[2], s1), (w.cat[1], s2), (w.cat[0], s3)]
@@ -568,9 +567,9 @@ class HipEngine:
             self._bn(w, i, pk, convs[i], Mo, bn_train)
             ops.bn_relu_apply(w.pre_c[i], w.bnp[i].scale, w.bnp[i].shift, d, Mo, cout, cout, d.shape[-1])
         # Fusion blocks: bilinear x2 of the previous stage (BN+ReLU fused into the gather) -> concat slice -> conv3x3
-        tb = taps("bilinear", G, s3, dev)
-        ops.resample2d(w.feat, w.cat[0].view(-1)[CONV_CH[3]:], tb, tb, B=B, h=G, w=G, H=s3, W=s3, C=D, ld_src=D,
-                       ld_dst=w.cat[0].shape[-1], src_bstride=G * G * D, dst_bstride=s3 * s3 * w.cat[0].shape[-1])
+        assert s3 == 2 * G
+        ops.upsample2x_bilinear(w.feat, w.cat[0].view(-1)[CONV_CH[3]:], B=B, h=G, w=G, C=D, ld_src=D,
+                                ld_dst=w.cat[0].shape[-1], src_bstride=G * G * D, dst_bstride=s3 * s3 * w.cat[0].shape[-1])
         res = [s3, s2, s1, S]
         for j in range(4):
             r = res[j]
@@ -590,10 +589,10 @@ class HipEngine:
             if j < 3:
                 nxt = w.cat[j + 1]
                 off = 0 if j == 2 else CONV_CH[2 - j]
-                t2 = taps("bilinear", r, 2 * r, dev)
-                ops.resample2d(w.pre_f[j], nxt.view(-1)[off:], t2, t2, B=B, h=r, w=r, H=2 * r, W=2 * r, C=FUS_OUT[j],
-                               ld_src=FUS_OUT[j], ld_dst=nxt.shape[-1], src_bstride=r * r * FUS_OUT[j],
-                               dst_bstride=4 * r * r * nxt.shape[-1], scale=w.bnp[i].scale, shift=w.bnp[i].shift)
+                ops.upsample2x_bilinear(w.pre_f[j], nxt.view(-1)[off:], B=B, h=r, w=r, C=FUS_OUT[j], ld_src=FUS_OUT[j],
+                                        ld_dst=nxt.shape[-1], src_bstride=r * r * FUS_OUT[j],
+                                        dst_bstride=4 * r * r * nxt.shape[-1], scale=w.bnp[i].scale, shift=w.bnp[i].shift,
+                                        extra8=w.img8 if j == 2 else None)
             else:
                 ops.bn_relu_apply(w.pre_f[3], w.bnp[i].scale, w.bnp[i].shift, w.F3, Mo, 32, 32, 32)
         # heads
@@ -734,16 +733,14 @@ class HipEngine:
                 off = 0 if j == 3 else CONV_CH[3 - j]
                 rp = res[j - 1]
                 cprev = FUS_OUT[j - 1]
-                ta = taps("bilinear", rp, r, dev, adjoint=True)
-                ops.resample2d(dcat.view(-1)[off:], w.dFpost[j - 1], ta, ta, B=B, h=r, w=r, H=rp, W=rp, C=cprev,
-                               ld_src=dcat.shape[-1], ld_dst=cprev, src_bstride=r * r * dcat.shape[-1],
-                               dst_bstride=rp * rp * cprev)
+                ops.upsample2x_bilinear_bwd(dcat.view(-1)[off:], w.dFpost[j - 1], B=B, h=rp, w=rp, C=cprev,
+                                            ld_dout=dcat.shape[-1], ld_din=cprev, dout_bstride=r * r * dcat.shape[-1],
+                                            din_bstride=rp * rp * cprev)
                 dy_post, ld_post = w.dFpost[j - 1], cprev
         # ---- encoder feature gradient: adjoint bilinear (s3 -> G), adjoint regrid (G -> token grid)
         dcat0 = w.dcat[0]
-        ta = taps("bilinear", G, s3, dev, adjoint=True)
-        ops.resample2d(dcat0.view(-1)[CONV_CH[3]:], w.dfeat, ta, ta, B=B, h=s3, w=s3, H=G, W=G, C=D, ld_src=dcat0.shape[-1],
-                       ld_dst=D, src_bstride=s3 * s3 * dcat0.shape[-1], dst_bstride=G * G * D)
+        ops.upsample2x_bilinear_bwd(dcat0.view(-1)[CONV_CH[3]:], w.dfeat, B=B, h=G, w=G, C=D, ld_dout=dcat0.shape[-1], ld_din=D,
+                                    dout_bstride=s3 * s3 * dcat0.shape[-1], din_bstride=G * G * D)
         mode = "bicubic" if c.patch != 16 else "identity"
         tr = taps(mode, c.grid, G, dev, adjoint=True)
         ops.resample2d(w.dfeat, w.dtok[c.prefix:], tr, tr, B=B, h=G, w=G, H=c.grid, W=c.grid, C=D, ld_src=D, ld_dst=D,

@@ -231,6 +231,20 @@ def resample2d(src, dst, taps_y, taps_x, *, B, h, w, H, W, C, ld_src, ld_dst, sr
           ld_src, ld_dst, src_bstride, dst_bstride, yi.shape[1])
 
 
+def upsample2x_bilinear(src, dst, *, B, h, w, C, ld_src, ld_dst, src_bstride, dst_bstride, scale=None, shift=None, extra8=None):
+    """bilinear x2 (align_corners=False) of an NHWC bf16 map into a channel slice of dst, producer BN+ReLU fused (scale/shift);
+    extra8: NHWC bf16 [B, 2h, 2w, 8] copied behind the C up-sampled channels"""
+    _chk_bf16(src, "src")
+    _call("mvit_upsample2x_bilinear", _p(src), _p(dst), _p(scale), _p(shift), _p(extra8), B, h, w, C, ld_src, ld_dst,
+          src_bstride, dst_bstride)
+
+
+def upsample2x_bilinear_bwd(d_out, d_in, *, B, h, w, C, ld_dout, ld_din, dout_bstride, din_bstride):
+    """adjoint of upsample2x_bilinear: d_in[B,h,w,:C] from d_out[B,2h,2w,:C] (both bf16, channel slices allowed)"""
+    _chk_bf16(d_out, "d_out")
+    _call("mvit_upsample2x_bilinear_bwd", _p(d_out), _p(d_in), B, h, w, C, ld_dout, ld_din, dout_bstride, din_bstride)
+
+
 def image_to_nhwc(img, dst, ld_dst, nzero=0):
     B, Cc, S, _ = img.shape
     _call("mvit_image_to_nhwc", _p(img), _p(dst), B, S, Cc, ld_dst, nzero)
