@@ -41,47 +41,63 @@ struct ResampleArgs {
   long long src_bstride, dst_bstride;
 };
 
+// blockIdx.y = (batch, output row): the row taps are block-uniform (scalar loads); the column taps of a thread's pixel are read
+// once, in front of the tap loops (TT = taps per axis when it is <= 4, else 0: dynamic count).
+template <int TT>
 __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs a) {
+  const int T = TT ? TT : a.T;
   const int cv = a.C >> 3;
-  const long long total = (long long)a.B * a.H * a.W * cv;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c8 = (int)(i % cv);
-    long long r = i / cv;
-    const int ox = (int)(r % a.W);
-    r /= a.W;
-    const int oy = (int)(r % a.H), b = (int)(r / a.H);
-    float acc[8];
+  const int b = blockIdx.y / a.H, oy = blockIdx.y - b * a.H;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.W * cv) return;
+  const int ox = i / cv, c8 = i - ox * cv;
+  float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    float sc[8], sh[8];
-    if (a.scale) {
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  float sc[8], sh[8];
+  if (a.scale) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sc[j] = a.scale[c8 * 8 + j], sh[j] = a.shift[c8 * 8 + j];
-    }
-    const bf16_t* sb = a.src + (size_t)b * a.src_bstride + c8 * 8;
-    for (int ty = 0; ty < a.T; ++ty) {
-      const float wy = a.ty_w[oy * a.T + ty];
-      if (wy == 0.f) continue;
-      const int iy = a.ty_idx[oy * a.T + ty];
-      for (int tx = 0; tx < a.T; ++tx) {
-        const float wx = a.tx_w[ox * a.T + tx];
-        if (wx == 0.f) continue;
-        const int ix = a.tx_idx[ox * a.T + tx];
-        const uint4 t = *(const uint4*)(sb + ((size_t)iy * a.w + ix) * a.ld_src);
-        float f[8];
-        unpack8(t, f);
-        const float wgt = wy * wx;
-        if (a.scale) {
+    for (int j = 0; j < 8; ++j) sc[j] = a.scale[c8 * 8 + j], sh[j] = a.shift[c8 * 8 + j];
+  }
+  constexpr int TR = TT ? TT : 1;
+  float wxr[TR];
+  int ixr[TR];
+  if (TT) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += wgt * fmaxf(f[j] * sc[j] + sh[j], 0.f);
-        } else {
+    for (int tx = 0; tx < TR; ++tx) wxr[tx] = a.tx_w[ox * T + tx], ixr[tx] = a.tx_idx[ox * T + tx];
+  }
+  const bf16_t* sb = a.src + (size_t)b * a.src_bstride + c8 * 8;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += wgt * f[j];
-        }
+  for (int ty = 0; ty < (TT ? TT : 16); ++ty) {
+    if (!TT && ty >= T) break;
+    const float wy = a.ty_w[oy * T + ty];
+    if (wy == 0.f) continue;
+    const int iy = a.ty_idx[oy * T + ty];
+    auto tap = [&](float wx, int ix) __attribute__((always_inline)) {
+      const uint4 t = *(const uint4*)(sb + ((size_t)iy * a.w + ix) * a.ld_src);
+      float f[8];
+      unpack8(t, f);
+      const float wgt = wy * wx;
+      if (a.scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wgt * fmaxf(f[j] * sc[j] + sh[j], 0.f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wgt * f[j];
+      }
+    };
+    if (TT) {
+#pragma unroll
+      for (int tx = 0; tx < TR; ++tx)
+        if (wxr[tx] != 0.f) tap(wxr[tx], ixr[tx]);
+    } else {
+      for (int tx = 0; tx < T; ++tx) {
+        const float wx = a.tx_w[ox * T + tx];
+        if (wx != 0.f) tap(wx, a.tx_idx[ox * T + tx]);
       }
     }
-    *(uint4*)(a.dst + (size_t)b * a.dst_bstride + ((size_t)oy * a.W + ox) * a.ld_dst + c8 * 8) = pack8f(acc);
   }
+  *(uint4*)(a.dst + (size_t)b * a.dst_bstride + ((size_t)oy * a.W + ox) * a.ld_dst + c8 * 8) = pack8f(acc);
 }
 
 // ------------------------------------------------------------------ bilinear x2 (align_corners=False), specialised
@@ -489,7 +505,16 @@ MVIT_API int mvit_resample2d(const void* src, void* dst, const int* ty_idx, cons
   if ((scale == nullptr) != (shift == nullptr)) return MVIT_EINVAL;
   ResampleArgs a{(const bf16_t*)src, (bf16_t*)dst, ty_idx, ty_w, tx_idx, tx_w, scale, shift, B, h, w, H, W, C,
                  ld_src, ld_dst, T, src_bstride, dst_bstride};
-  hipLaunchKernelGGL(resample_kernel, dim3(nblk((long long)B * H * W * (C >> 3), 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if ((long long)B * H > 65535) return MVIT_EINVAL;
+  const dim3 grid((unsigned)((W * (C >> 3) + 255) / 256), (unsigned)(B * H));
+  hipStream_t s = (hipStream_t)stream;
+  switch (T) {
+    case 1: hipLaunchKernelGGL(resample_kernel<1>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(resample_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(resample_kernel<3>, grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(resample_kernel<4>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(resample_kernel<0>, grid, dim3(256), 0, s, a); break;
+  }
   return MVIT_LAUNCH_CHECK();
 }
 
