@@ -193,6 +193,12 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
  * wk [Cout, 9*Cp] (forward), wd [Cp, 9*Cout] (dgrad, may be NULL); packed channel c = source channel (c+rot) mod Cin */
 MVIT_API int mvit_pack_conv3x3_weights(const float* W, void* wk, void* wd, int Cout, int Cin, int Cp, int rot,
                                        mvit_stream_t stream);
+/* The same for up to 8 weights in one launch (the decoder's seven convolutions are re-packed every training step). */
+typedef struct mvit_conv_pack_desc {
+  const float* W; void* wk; void* wd;   /* wd may be NULL */
+  int Cout, Cin, Cp, rot;
+} mvit_conv_pack_desc;
+MVIT_API int mvit_pack_conv3x3_weights_multi(const mvit_conv_pack_desc* descs, int n, mvit_stream_t stream);
 /* ConvTranspose2d(k=2, s=2) output placement (src/generators/unet.py:304-372,490-498): the GEMM result packed[M, 4*C]
  * (column (dy*2+dx)*C + c) <-> NHWC image [B, 2H, 2W] with row stride ld_img (a channel slice of a concat buffer).
  * inverse = 0: packed -> image; 1: image gradient -> packed. */
@@ -276,6 +282,12 @@ MVIT_API int mvit_lora_pack(const float* lora, void* AcatT, void* Acat, void* B2
  * rotation); accumulate != 0 adds to dW. */
 MVIT_API int mvit_unpack_conv3x3_wgrad(const float* dWt, float* dW, int Cout, int Cin, int Cp, int rot, int accumulate,
                                        int n_major, mvit_stream_t stream);
+/* The same for up to 8 gradients in one launch. */
+typedef struct mvit_conv_unpack_desc {
+  const float* dWt; float* dW;
+  int Cout, Cin, Cp, rot, accumulate, n_major;
+} mvit_conv_unpack_desc;
+MVIT_API int mvit_unpack_conv3x3_wgrad_multi(const mvit_conv_unpack_desc* descs, int n, mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- loss / optimiser */
 /* WeightedMSELoss (src/loss.py:47-57): loss_acc += sum_c w_c sum (p-t)^2 (caller multiplies by lambda/(C*B*HW));

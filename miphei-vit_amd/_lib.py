@@ -40,6 +40,14 @@ class GemmTnArgs(C.Structure):
                 ("strideA", ll), ("strideB", ll), ("strideC", ll)]
 
 
+class ConvPackDesc(C.Structure):
+    _fields_ = [("W", vp), ("wk", vp), ("wd", vp), ("Cout", ci), ("Cin", ci), ("Cp", ci), ("rot", ci)]
+
+
+class ConvUnpackDesc(C.Structure):
+    _fields_ = [("dWt", vp), ("dW", vp), ("Cout", ci), ("Cin", ci), ("Cp", ci), ("rot", ci), ("accumulate", ci), ("n_major", ci)]
+
+
 # name -> argtypes (restype is always int); mirrors include/miphei_hip.h
 SIGNATURES = {
     "mvit_gemm_bf16": [C.POINTER(GemmArgs), vp],
@@ -63,6 +71,8 @@ SIGNATURES = {
     "mvit_attention_fwd": [vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_attention_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_resample2d": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ll, ll, ci, vp],
+    "mvit_pack_conv3x3_weights_multi": [C.POINTER(ConvPackDesc), ci, vp],
+    "mvit_unpack_conv3x3_wgrad_multi": [C.POINTER(ConvUnpackDesc), ci, vp],
     "mvit_upsample2x_bilinear": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ll, ll, vp],
     "mvit_upsample2x_bilinear_bwd": [vp, vp, ci, ci, ci, ci, ci, ci, ll, ll, vp],
     "mvit_image_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],

@@ -436,12 +436,20 @@ inline int nblk(long long work, int per, int cap = 16384) {
 // W [Cout, Cin, 3, 3] f32 (nn.Conv2d layout)  ->  wk [Cout, 9*Cp] bf16, k = (ky*3+kx)*Cp + c   (B operand of the forward
 // implicit GEMM) and wd [Cp, 9*Cout] bf16, k = (ky*3+kx)*Cout + co (B operand of the dgrad GEMM).  Channel c of the
 // packed layout is source channel (c + rot) mod Cin (fus3 keeps its concat buffer as [up | image]); c >= Cin is zero pad.
-__global__ __launch_bounds__(256) void pack_conv_w_kernel(const float* __restrict__ W, bf16_t* __restrict__ wk,
-                                                          bf16_t* __restrict__ wd, int Cout, int Cin, int Cp, int rot) {
+// Up to 8 weights per launch (blockIdx.y = weight, blockIdx.z = 0: wk / 1: wd): the seven convolutions of the decoder are re-packed
+// every step, and a dependent 6 us launch each is what they cost.
+struct PackBatch { mvit_conv_pack_desc d[8]; };
+__global__ __launch_bounds__(256) void pack_conv_w_kernel(const PackBatch pb) {
+  const mvit_conv_pack_desc& q = pb.d[blockIdx.y];
+  const float* __restrict__ W = q.W;
+  bf16_t* __restrict__ wk = (bf16_t*)q.wk;
+  bf16_t* __restrict__ wd = (bf16_t*)q.wd;
+  const int Cout = q.Cout, Cin = q.Cin, Cp = q.Cp, rot = q.rot;
+  if (blockIdx.z == 1 && !wd) return;
   const int total = Cout * Cp;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     int co, c;
-    if (blockIdx.y == 0) {  // c fastest: coalesced wk stores
+    if (blockIdx.z == 0) {  // c fastest: coalesced wk stores
       co = i / Cp, c = i - co * Cp;
     } else {                // co fastest: coalesced wd stores
       c = i / Cout, co = i - c * Cout;
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(256) void pack_conv_w_kernel(const float* __restric
 #pragma unroll
       for (int t = 0; t < 9; ++t) v[t] = 0.f;
     }
-    if (blockIdx.y == 0) {
+    if (blockIdx.z == 0) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) wk[(size_t)co * 9 * Cp + (size_t)t * Cp + c] = f2bf(v[t]);
     } else {
@@ -606,9 +614,23 @@ MVIT_API int mvit_pack_conv3x3_weights(const float* W, void* wk, void* wd, int C
                                        mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (Cout <= 0 || Cin <= 0 || Cp < Cin || (Cp & 7) || rot < 0 || !wk) return MVIT_EINVAL;
-  const int total = Cout * Cp;
-  hipLaunchKernelGGL(pack_conv_w_kernel, dim3(min((total + 255) / 256, 2048), wd ? 2 : 1), dim3(256), 0, (hipStream_t)stream, W,
-                     (bf16_t*)wk, (bf16_t*)wd, Cout, Cin, Cp, rot);
+  mvit_conv_pack_desc d{W, wk, wd, Cout, Cin, Cp, rot};
+  return mvit_pack_conv3x3_weights_multi(&d, 1, stream);
+}
+
+MVIT_API int mvit_pack_conv3x3_weights_multi(const mvit_conv_pack_desc* descs, int n, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!descs || n <= 0 || n > 8) return MVIT_EINVAL;
+  PackBatch pb{};
+  int most = 0, any_wd = 0;
+  for (int i = 0; i < n; ++i) {
+    const mvit_conv_pack_desc& q = descs[i];
+    if (q.Cout <= 0 || q.Cin <= 0 || q.Cp < q.Cin || (q.Cp & 7) || q.rot < 0 || !q.wk || !q.W) return MVIT_EINVAL;
+    pb.d[i] = q;
+    most = max(most, q.Cout * q.Cp);
+    any_wd |= q.wd != nullptr;
+  }
+  hipLaunchKernelGGL(pack_conv_w_kernel, dim3(min((most + 255) / 256, 1024), n, any_wd ? 2 : 1), dim3(256), 0, (hipStream_t)stream, pb);
   return MVIT_LAUNCH_CHECK();
 }
 

@@ -48,14 +48,18 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 // dWt [(ky,kx,c_pad), Cout] f32 (output of the TN weight-gradient GEMM; n_major: [Cout, (ky,kx,c_pad)], the direct kernel's)
 // -> parameter layout dW [Cout, Cin, 3, 3];
 // packed channel c is parameter channel (c + rot) mod Cin (see pack_conv_w_kernel); the Cp - Cin pad rows are dropped.
-__global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const float* __restrict__ dWt, float* __restrict__ dW, int Cout,
-                                                                int Cin, int Cp, int rot, int accumulate, int n_major) {
+struct UnpackBatch { mvit_conv_unpack_desc d[8]; };   // (up to 8 gradients per launch, blockIdx.y = gradient)
+__global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const UnpackBatch ub) {
+  const mvit_conv_unpack_desc& q = ub.d[blockIdx.y];
+  const float* __restrict__ dWt = q.dWt;
+  float* __restrict__ dW = q.dW;
+  const int Cout = q.Cout, Cin = q.Cin, Cp = q.Cp, rot = q.rot;
   const int total = Cout * Cin * 9;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int t = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
     const int c = (ci - rot % Cin + Cin) % Cin;
-    const float v = n_major ? dWt[(size_t)co * 9 * Cp + (size_t)t * Cp + c] : dWt[((size_t)t * Cp + c) * Cout + co];
-    dW[i] = accumulate ? dW[i] + v : v;
+    const float v = q.n_major ? dWt[(size_t)co * 9 * Cp + (size_t)t * Cp + c] : dWt[((size_t)t * Cp + c) * Cout + co];
+    dW[i] = q.accumulate ? dW[i] + v : v;
   }
 }
 
@@ -76,10 +80,23 @@ MVIT_API int mvit_lora_pack(const float* lora, void* AcatT, void* Acat, void* B2
 MVIT_API int mvit_unpack_conv3x3_wgrad(const float* dWt, float* dW, int Cout, int Cin, int Cp, int rot, int accumulate,
                                        int n_major, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
-  if (!dWt || !dW || Cout <= 0 || Cin <= 0 || Cp < Cin || rot < 0) return MVIT_EINVAL;
-  const int total = Cout * Cin * 9;
-  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, dWt, dW, Cout, Cin, Cp, rot, accumulate, n_major);
+  mvit_conv_unpack_desc d{dWt, dW, Cout, Cin, Cp, rot, accumulate, n_major};
+  return mvit_unpack_conv3x3_wgrad_multi(&d, 1, stream);
+}
+
+MVIT_API int mvit_unpack_conv3x3_wgrad_multi(const mvit_conv_unpack_desc* descs, int n, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!descs || n <= 0 || n > 8) return MVIT_EINVAL;
+  UnpackBatch ub{};
+  int most = 0;
+  for (int i = 0; i < n; ++i) {
+    const mvit_conv_unpack_desc& q = descs[i];
+    if (!q.dWt || !q.dW || q.Cout <= 0 || q.Cin <= 0 || q.Cp < q.Cin || q.rot < 0) return MVIT_EINVAL;
+    ub.d[i] = q;
+    most = most > q.Cout * q.Cin * 9 ? most : q.Cout * q.Cin * 9;
+  }
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256, n), dim3(256), 0,
+                     (hipStream_t)stream, ub);
   return MVIT_LAUNCH_CHECK();
 }
 

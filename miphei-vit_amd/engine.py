@@ -316,6 +316,7 @@ class HipEngine:
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
         pk.wdir_f = pk.wdir_b = None
+        packs = []
         for i, cv in enumerate(convs):
             w = f32(cv.conv.weight).contiguous()                                    # [Cout, Cin, 3, 3]
             cout, cin = w.shape[0], w.shape[1]
@@ -324,7 +325,7 @@ class HipEngine:
             cp = _pad8(cin)
             wk = torch.empty(cout, 9 * cp, device=dev, dtype=bf)
             wd = torch.empty(cp, 9 * cout, device=dev, dtype=bf) if need_bwd else None
-            ops.pack_conv3x3_weights(w, wk, wd, rot=3 if last else 0)               # one launch instead of ~10 torch ops
+            packs.append((w, wk, wd, 3 if last else 0))
             pk.wk.append(wk)
             if need_bwd:
                 pk.wd.append(wd)
@@ -337,6 +338,7 @@ class HipEngine:
             pk.cin.append(cin)
             pk.cin_pad.append(cp)
             pk.perm.append(perm)
+        ops.pack_conv3x3_weights_multi(packs)      # all seven in one launch
         heads = self._heads()
         st = lambda get, shape: torch.stack([f32(get(h)).reshape(-1) for h in heads]).reshape(shape).contiguous()
         NH = c.NH
@@ -762,9 +764,9 @@ class HipEngine:
                 ops.gemm(w.dpre_c[i], pk.wd[i], tgt, M=B * r_in * r_in, N=cin, amode=A_CONV3_T,
                          conv=(r_out, r_out, cout, cout, r_in, r_in, 2), ldc=tgt.shape[-1], flags=ACCUM_BF16)
         # conv weight gradients: dWt [(ky,kx,c_pad), cout] -> parameter layout [cout, cin, ky, kx]
-        for i, cv in enumerate(convs):
-            ops.unpack_conv3x3_wgrad(w.dWt[i], fl.gview[id(cv.conv.weight)], pk.cin_pad[i], rot=3 if pk.perm[i] is not None else 0,
-                                     n_major=(i == len(convs) - 1 and getattr(w, "wgrad_n_major", False)))
+        ops.unpack_conv3x3_wgrad_multi([(w.dWt[i], fl.gview[id(cv.conv.weight)], pk.cin_pad[i], 3 if pk.perm[i] is not None else 0,
+                                         i == len(convs) - 1 and getattr(w, "wgrad_n_major", False))
+                                        for i, cv in enumerate(convs)])
         if on_decoder_done is not None:
             on_decoder_done()
         # ---- encoder (LoRA gradients; frozen weights need dgrad only)

@@ -292,6 +292,30 @@ def pack_conv3x3_weights(W, wk, wd, rot=0):
     _call("mvit_pack_conv3x3_weights", _p(W), _p(wk), _p(wd), cout, cin, cp, rot)
 
 
+def pack_conv3x3_weights_multi(items):
+    """items: [(W, wk, wd or None, rot)], at most 8 per launch (longer lists are split)"""
+    for i0 in range(0, len(items), 8):
+        part = items[i0:i0 + 8]
+        arr = (L.ConvPackDesc * len(part))()
+        for d, (W, wk, wd, rot) in zip(arr, part):
+            assert W.dtype == torch.float32 and W.is_contiguous()
+            d.W, d.wk, d.wd = W.data_ptr(), wk.data_ptr(), None if wd is None else wd.data_ptr()
+            d.Cout, d.Cin, d.Cp, d.rot = W.shape[0], W.shape[1], wk.shape[1] // 9, rot
+        L.check(L.lib().mvit_pack_conv3x3_weights_multi(arr, len(part), _stream()), "mvit_pack_conv3x3_weights_multi")
+
+
+def unpack_conv3x3_wgrad_multi(items):
+    """items: [(dWt, dW, cin_pad, rot, n_major)], at most 8 per launch (longer lists are split)"""
+    for i0 in range(0, len(items), 8):
+        part = items[i0:i0 + 8]
+        arr = (L.ConvUnpackDesc * len(part))()
+        for d, (dWt, dW, cp, rot, n_major) in zip(arr, part):
+            assert dWt.dtype == torch.float32 and dW.dtype == torch.float32 and dW.is_contiguous()
+            d.dWt, d.dW = dWt.data_ptr(), dW.data_ptr()
+            d.Cout, d.Cin, d.Cp, d.rot, d.accumulate, d.n_major = dW.shape[0], dW.shape[1], cp, rot, 0, int(n_major)
+        L.check(L.lib().mvit_unpack_conv3x3_wgrad_multi(arr, len(part), _stream()), "mvit_unpack_conv3x3_wgrad_multi")
+
+
 def conv3x3_direct_supported(cin_pad, cout):
     return bool(L.lib().mvit_conv3x3_direct_supported(cin_pad, cout))
 

@@ -94,7 +94,10 @@ def test_optimizer_state_survives_reflatten_and_checkpoint_resume():
         if moved == 0.0:          # bias in front of a train-mode BatchNorm: its gradient is exactly zero
             assert d == 0.0, k
             continue
-        assert moved > 1e-3 and d < 0.1 * moved, (k, d, moved)
+        # (single elements with a near-zero gradient sit closest to the noise: the bound on the maximum is looser than the one
+        # on the norm of the whole tensor)
+        dn, mn = float((got4[k] - ref4[k]).norm()), float((ref4[k] - p3[k]).norm())
+        assert moved > 1e-3 and dn < 0.1 * mn and d < 0.5 * moved, (k, d, moved, dn, mn)
     # (c) a state of another architecture is rejected
     bad = dict(ckpt["optimizer_state"], layout=ckpt["optimizer_state"]["layout"][:-1])
     with pytest.raises(RuntimeError, match="optimizer state does not match"):
