@@ -296,10 +296,17 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # roofline leg: HIP events around the launches of the dominant kernel, on a SAMPLE of the timed steps (every probe_every-th,
+    # at least one): an event pair costs the stream ~6 us of idle time per launch, which on all 159 launches of every step was
+    # 2.9 % of the headline number (395 vs 406.5 tiles/s same box)
     ops.PROBE.start()
+    ops.PROBE.on = False
+    probe_every = max(1, a.steps // 5)
     t0 = time.perf_counter()
     for i in range(a.steps):
+        ops.PROBE.on = (i % probe_every == 0)
         step(a.warmup + i)
+    ops.PROBE.on = True
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -360,7 +367,9 @@ def main(argv=None):
             res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE> (8 waves)",
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16, 4), "traffic": traffic, "traffic_source": src,
-                               "launches": probe["n"], "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2)}
+                               "launches": probe["n"], "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2),
+                               "sampled_steps": len(range(0, a.steps, probe_every)),
+                               "note": "HIP events on the stream around every launch of this kernel in the sampled timed steps"}
         if not a.no_cpu_baseline and world == 1 and a.mode == "train" and not unet:
             res["cpu_baseline"], res["parity"] = cpu_baseline(model, a, nc, weights, dev)
     # RCCL's banner sits in the C-level stdout buffer until that is flushed (normally at exit, i.e. AFTER anything Python
