@@ -101,6 +101,7 @@ def parse_args(argv=None):
     ap.add_argument("--metrics", type=int, default=0, help="train mode: also run the per-step PSNR/SSIM state update of the "
                     "reference (models.py:140-143); the headline number is taken with it off (SURVEY.md section 6)")
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
+    ap.add_argument("--probe", type=int, default=1, help="0: no HIP-event probe of the dominant kernel (no `roofline` object)")
     ap.add_argument("--lora-group", type=int, default=0, help="ViT blocks per batched LoRA weight-gradient launch (0 = engine default)")
     ap.add_argument("--lora-buckets", type=int, default=4, help="sub-buckets of the LoRA gradient all-reduce (N > 1)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL; gloo only with --dry")
@@ -304,7 +305,7 @@ def main(argv=None):
     probe_every = max(1, a.steps // 5)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        ops.PROBE.on = (i % probe_every == 0)
+        ops.PROBE.on = bool(a.probe) and (i % probe_every == 0)
         step(a.warmup + i)
     ops.PROBE.on = True
     torch.cuda.synchronize()
