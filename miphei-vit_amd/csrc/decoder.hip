@@ -41,13 +41,13 @@ struct ResampleArgs {
   long long src_bstride, dst_bstride;
 };
 
-// blockIdx.y = (batch, output row): the row taps are block-uniform (scalar loads); the column taps of a thread's pixel are read
+// blockIdx.y = output row, blockIdx.z = batch: the row taps are block-uniform (scalar loads); the column taps of a thread's pixel are read
 // once, in front of the tap loops (TT = taps per axis when it is <= 4, else 0: dynamic count).
 template <int TT>
 __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs a) {
   const int T = TT ? TT : a.T;
   const int cv = a.C >> 3;
-  const int b = blockIdx.y / a.H, oy = blockIdx.y - b * a.H;
+  const int b = blockIdx.z, oy = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.W * cv) return;
   const int ox = i / cv, c8 = i - ox * cv;
@@ -513,8 +513,8 @@ MVIT_API int mvit_resample2d(const void* src, void* dst, const int* ty_idx, cons
   if ((scale == nullptr) != (shift == nullptr)) return MVIT_EINVAL;
   ResampleArgs a{(const bf16_t*)src, (bf16_t*)dst, ty_idx, ty_w, tx_idx, tx_w, scale, shift, B, h, w, H, W, C,
                  ld_src, ld_dst, T, src_bstride, dst_bstride};
-  if ((long long)B * H > 65535) return MVIT_EINVAL;
-  const dim3 grid((unsigned)((W * (C >> 3) + 255) / 256), (unsigned)(B * H));
+  if (H > 65535 || B > 65535) return MVIT_EINVAL;
+  const dim3 grid((unsigned)((W * (C >> 3) + 255) / 256), (unsigned)H, (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
   switch (T) {
     case 1: hipLaunchKernelGGL(resample_kernel<1>, grid, dim3(256), 0, s, a); break;
