@@ -164,3 +164,30 @@ def test_lora_pack_and_conv_wgrad_unpack():
         dwn = dWt.view(9, cp, cout).permute(2, 0, 1).contiguous()       # the direct kernel's output-channel-major layout
         ops.unpack_conv3x3_wgrad(dwn, dW, cp, rot=rot, n_major=True)
         assert torch.equal(dW, want)
+
+
+def test_conv_weight_pack_unpack_multi():
+    """the *_multi entry points (all decoder conv weights per launch) give exactly what the single-weight calls give; more than
+    8 descriptors are split over launches"""
+    ops = _ops()
+    shapes = [(48, 3, 8, 0), (96, 48, 48, 0), (192, 96, 96, 0), (256, 1728, 1728, 0), (128, 352, 352, 0), (64, 176, 176, 0),
+              (32, 67, 72, 3), (16, 8, 8, 0), (24, 16, 16, 0)]
+    bf = torch.bfloat16
+    Ws = [_rand(co, ci, 3, 3, seed=co + ci, scale=0.05) for co, ci, _, _ in shapes]
+    single, multi = [], []
+    for W, (co, ci, cp, rot) in zip(Ws, shapes):
+        wk, wd = torch.empty(co, 9 * cp, device="cuda", dtype=bf), torch.empty(cp, 9 * co, device="cuda", dtype=bf)
+        ops.pack_conv3x3_weights(W, wk, wd, rot=rot)
+        single.append((wk, wd))
+        multi.append((W, torch.zeros_like(wk), torch.zeros_like(wd) if co != 16 else None, rot))     # one entry without wd
+    ops.pack_conv3x3_weights_multi(multi)
+    for (wk, wd), (_, wk2, wd2, _) in zip(single, multi):
+        assert torch.equal(wk, wk2) and (wd2 is None or torch.equal(wd, wd2))
+    dWts = [_rand(9 * cp, co, seed=7 + co) for co, _, cp, _ in shapes]
+    one = [torch.empty(co, ci, 3, 3, device="cuda") for co, ci, _, _ in shapes]
+    many = [torch.zeros(co, ci, 3, 3, device="cuda") for co, ci, _, _ in shapes]
+    for dWt, dW, (_, _, cp, rot) in zip(dWts, one, shapes):
+        ops.unpack_conv3x3_wgrad(dWt, dW, cp, rot=rot)
+    ops.unpack_conv3x3_wgrad_multi([(dWt, dW, cp, rot, False) for dWt, dW, (_, _, cp, rot) in zip(dWts, many, shapes)])
+    for a, b in zip(one, many):
+        assert torch.equal(a, b)
