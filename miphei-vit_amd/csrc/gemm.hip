@@ -46,9 +46,10 @@ static int select_variant(const mvit_gemm_args& a) {
   MVIT_KNOB(big_tile, "MVIT_GEMM_BIG_TILE", 1);
   const bool big = big_tile && a.M >= 1024;  // 8-wave 256x128 tile, 3-stage DMA pipeline
   // 8-wave 256x256 tile (2 stages): 1.5x the arithmetic intensity per DMA'd byte, but its two stages leave the refill less
-  // than one K step of lead and M = 5264 quantises badly on it; measured inside the model it wins only from about four
-  // rounds of tiles over the chip (batch-64 inference +0.6 %; the batch-16 training step is 0.8 % faster without it)
-  MVIT_KNOB(huge_min_tiles, "MVIT_GEMM_HUGE_MIN_TILES", 1024);
+  // than one K step of lead and M = 5264 quantises badly on it; measured inside the model it wins from about 2.6 rounds of
+  // tiles over the chip: fc1 of the batch-16 training step (672 tiles: +0.45 % on the step, same box, two pairs of runs) and
+  // everything at batch-64 inference (+0.6 %); with qkv (378 tiles) and dfc2 (336) on it the step is 2 % slower
+  MVIT_KNOB(huge_min_tiles, "MVIT_GEMM_HUGE_MIN_TILES", 600);
   const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const bool huge = big && dense && (a.N % 256 == 0) && tiles256 >= huge_min_tiles && a.ksplit <= 1;
   // one-wave-per-SIMD variants (4 waves, 128-row sub-tiles), kept for measurement: MVIT_GEMM_W4 bit 0 sends the 256x256
