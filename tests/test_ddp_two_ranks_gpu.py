@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, port, lora_buckets, lora_group, ret):
+def _worker(rank, port, lora_buckets, lora_group, unetr, ret):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
     dist.init_process_group("gloo", rank=rank, world_size=2)
@@ -33,34 +33,57 @@ def _worker(rank, port, lora_buckets, lora_group, ret):
         from miphei_vit_amd.models import ModelModule
         from miphei_vit_amd.trainer import DataParallelSync
         cfgname, img, nc, B = "tiny4_swiglu", 128, 3, 2
-        sd = det_state_dict(generator_state_shapes(VIT_CONFIGS[cfgname], img, nc), seed=5 + rank, layerscale=0.5)   # ranks start apart
-        model = get_vitmatte(cfgname, img, nc, use_lora=True, pretrained=False)
-        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        if unetr:
+            from miphei_vit_amd.generators.unet import Unet
+            torch.manual_seed(0)                                    # the frozen encoder is the same checkpoint on every rank
+            model = Unet(img, cfgname, use_lora=True, classes=nc, pretrained=False)
+            torch.manual_seed(1 + rank)
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    if p_.requires_grad:
+                        p_.add_(0.01 * torch.randn_like(p_))         # ranks start apart in everything that is exchanged
+        else:
+            sd = det_state_dict(generator_state_shapes(VIT_CONFIGS[cfgname], img, nc), seed=5, layerscale=0.5)
+            model = get_vitmatte(cfgname, img, nc, use_lora=True, pretrained=False)
+            model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+            torch.manual_seed(1 + rank)
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    if p_.requires_grad:
+                        p_.add_(0.01 * torch.randn_like(p_))
         model.cuda()
         eng = model._engine
-        eng.lora_group = lora_group
+        enc = eng._encoder_engine() if hasattr(eng, "_encoder_engine") else eng
+        enc.lora_group = lora_group
         mod = ModelModule(model, None, 1e-3, 0., WeightedMSELoss(50.0, orion_marker_weights(nc)))
         mod.total_iters = 100
         sync = DataParallelSync(eng, lora_buckets=lora_buckets)
         assert sync.active and sync.world == 2
+        cat = lambda kind: torch.cat([b.reshape(-1) for b in sync._buffers(kind)])
+        if hasattr(eng, "_ensure_flat"):
+            eng._ensure_flat()
+        before = cat("param").clone()
         sync.broadcast_parameters(0)
-        flat = eng._ensure_flat().flat
+        flat = cat("param")
         both = [torch.empty_like(flat) for _ in range(2)]
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1])                       # broadcast: rank 1 now holds rank 0's parameters
+        assert rank == 0 or not torch.equal(before, flat)
         x, y = synth_batch(100 + rank, B, img, nc)                  # a different minibatch per rank
-        x, y = x.cuda(), y.cuda()
+        x, y = x.cuda(), (y if rank == 0 else -y).cuda()           # (and mirrored targets: the two local gradients point apart)
         w = mod.loss_reconstruct.marker_weights.cuda()
+
+        bwd = getattr(eng, "backward_fused", eng.backward)
 
         def grads(synced):
             out = eng.forward(x, train=True)
             _, dY = eng.loss_and_grad(out, y, w, 50.0)
             if synced:
-                eng.backward(dY, on_decoder_done=sync.decoder_ready, on_lora_block_done=sync.lora_block_done)
+                bwd(dY, on_decoder_done=sync.decoder_ready, on_lora_block_done=sync.lora_block_done)
                 sync.finish()
             else:
-                eng.backward(dY)
-            return eng._flat.gflat.clone()
+                bwd(dY)
+            return cat("grad").clone()
 
         g_local = grads(False)
         g_sync = grads(True)
@@ -68,25 +91,27 @@ def _worker(rank, port, lora_buckets, lora_group, ret):
         dist.all_gather(gl, g_local)
         mean = 0.5 * (gl[0] + gl[1])
         rel = float((g_sync - mean).norm() / mean.norm())
-        n_lora = eng.lora_blocks() * 4 * 8 * VIT_CONFIGS[cfgname].dim
-        rel_lora = float((g_sync[:n_lora] - mean[:n_lora]).norm() / mean[:n_lora].norm())
+        _, lora = eng.grad_buckets()
+        n_lora = lora.numel()
+        lo = slice(0, n_lora) if not unetr else slice(g_sync.numel() - n_lora, g_sync.numel())   # (UNETR: the LoRA buffer comes last)
+        rel_lora = float((g_sync[lo] - mean[lo]).norm() / mean[lo].norm())
         apart = float((gl[0] - gl[1]).norm() / mean.norm())        # the two ranks' gradients really differ
         # (2) a full step with the exchange: identical parameters on both ranks
         mod.grad_sync = sync
         mod.training_step({"image": x, "target": y}, 0)
-        dist.all_gather(both, eng._flat.flat)
+        dist.all_gather(both, cat("param"))
         same = bool(torch.equal(both[0], both[1]))
         ret[rank] = (rel, rel_lora, apart, same)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lora_buckets,lora_group", [(2, 10), (3, 3), (4, 1)])
-def test_two_rank_exchange_with_the_hip_engine(lora_buckets, lora_group):
+@pytest.mark.parametrize("lora_buckets,lora_group,unetr", [(2, 10, False), (3, 3, False), (4, 1, False), (2, 10, True)])
+def test_two_rank_exchange_with_the_hip_engine(lora_buckets, lora_group, unetr):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(_free_port(), lora_buckets, lora_group, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(_free_port(), lora_buckets, lora_group, unetr, ret), nprocs=2, join=True)
     assert len(ret) == 2
     for rank in (0, 1):
         rel, rel_lora, apart, same = ret[rank]
