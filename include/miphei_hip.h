@@ -319,10 +319,11 @@ MVIT_API int mvit_f32_to_u8_export(const float* src, void* dst_u8, long long n, 
  * 'nearest-exact' of the label map when scale_factor < 1, then per image torch.unique + scatter_add_ + divide) and the reduction of
  * CellMetrics.update (src/metrics.py:38-74; want_sums != 0 returns sums instead of means).
  *   pred / target: f32 [B,C,H,W] (target may be NULL), nuclei: int32 or int64 [B,H,W], C <= 32, 0 < scale_factor <= 1.
- *   scratch: rec_count [B] int, rec_key [B,rmax] int, rec_val [B,rmax,2C+1] f32 (rmax a power of two <= 8192: partial records
+ *   scratch: rec_count [B] int, rec_key [B,rmax] int, rec_val [B,rmax,2C+1] f32 (rmax a power of two <= 16384: partial records
  *   per image, one per (tile, nucleus) pair).
  *   outputs, per image b: n_unique[b]; rows [b, 0 .. n_unique[b]) of out_ids (ascending), out_count, out_pred [.,C], out_target.
- * A host that finds rec_count[b] > rmax must treat the result as invalid (more nucleus fragments than the scratch holds). */
+ * A host that finds rec_count[b] > rmax must treat the result as invalid (more nucleus fragments than the scratch holds) and retry
+ * with a larger rmax or on row chunks of the images; int64 labels above INT32_MAX are not representable (the host checks). */
 MVIT_API int mvit_cell_means(const float* pred, const float* target, const void* nuclei, int label_is_int64, int B, int C, int H,
                              int W, float scale_factor, int rmax, int want_sums, int* rec_count, int* rec_key, float* rec_val,
                              int* n_unique, int* out_ids, float* out_count, float* out_pred, float* out_target,

@@ -47,6 +47,20 @@ def save_pruned_safetensors(generator, path):
     return sorted(sd)
 
 
+def save_checkpoint_atomic(state, path):
+    """``torch.save`` into a temporary file in the same directory, then ``os.replace``: a crash in the middle of a write leaves
+    the previous resume point intact (the reference's Lightning ``ModelCheckpoint`` writes through a temporary file as well)."""
+    path = str(path)
+    tmp = f"{path}.tmp.{os.getpid()}"
+    try:
+        torch.save(state, tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return path
+
+
 def load_generator_checkpoint(generator, checkpoint_dir):
     """``model.safetensors`` (LoRA + decoder, strict=False + validation) or ``model.weights.ckpt`` (Lightning)."""
     st = os.path.join(str(checkpoint_dir), "model.safetensors")
@@ -56,5 +70,5 @@ def load_generator_checkpoint(generator, checkpoint_dir):
         validate_load_info(info)
         return info
     ck = os.path.join(str(checkpoint_dir), "model.weights.ckpt")
-    sd = get_generator_state_dict(torch.load(ck, map_location="cpu")["state_dict"])
+    sd = get_generator_state_dict(torch.load(ck, map_location="cpu", weights_only=True)["state_dict"])
     return generator.load_state_dict(sd)

@@ -31,7 +31,7 @@ struct CellGeom {
 __device__ __forceinline__ int load_label(const void* nuclei, size_t i, int lab64) {
   if (lab64) {
     const long long v = ((const long long*)nuclei)[i];
-    return v > 0x7fffffffLL ? -1 : (int)v;     // ids beyond int32 are reported by the host wrapper (never seen in practice)
+    return v > 0x7fffffffLL ? -1 : (int)v;     // ids beyond int32: cells.py checks nuclei.max() on the host and raises before the launch
   }
   return ((const int*)nuclei)[i];
 }
@@ -245,7 +245,7 @@ MVIT_API int mvit_cell_means(const float* pred, const float* target, const void*
                              mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (!pred || !nuclei || B <= 0 || C <= 0 || C > 32 || H <= 0 || W <= 0 || !(scale_factor > 0.f) || scale_factor > 1.f ||
-      rmax < 2 || rmax > 8192 || (rmax & (rmax - 1)) || !rec_count || !rec_key || !rec_val || !n_unique || !out_ids || !out_count || !out_pred)
+      rmax < 2 || rmax > 16384 || (rmax & (rmax - 1)) || !rec_count || !rec_key || !rec_val || !n_unique || !out_ids || !out_count || !out_pred)
     return MVIT_EINVAL;
   CellGeom g;
   g.B = B, g.C = C, g.H = H, g.W = W;

@@ -121,24 +121,25 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
       }
   }
   __syncthreads();
-  if (wave >= 4) return;
-  // t block [16 tokens][16 columns]: K steps of 32, step ks handled by wave ks % 4
+  // t block [16 tokens][16 columns]: K steps of 32, step ks handled by wave ks % 4.  Every wave of the block stays alive through
+  // the second barrier (waves 4.. only wait there): nothing relies on how the hardware counts exited waves at a barrier.
   const int r16 = lane & 15, kq = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const char* ha = Hs + (r16 & (LNL_ROWS - 1)) * RS + kq * 16;   // (rows beyond LNL_ROWS repeat: their results are not stored)
-  const char* ab = As + r16 * RS + kq * 16;
-  const int nks = D >> 5;
-  for (int ks = wave; ks < nks; ks += 4) {
-    const bf16x8 fa = *(const bf16x8*)(ha + ks * 64);
-    const bf16x8 fb = *(const bf16x8*)(ab + ks * 64);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
-  }
-  if (wave > 0) {
+  if (wave < 4) {
+    const char* ha = Hs + (r16 & (LNL_ROWS - 1)) * RS + kq * 16;   // (rows beyond LNL_ROWS repeat: their results are not stored)
+    const char* ab = As + r16 * RS + kq * 16;
+    const int nks = D >> 5;
+    for (int ks = wave; ks < nks; ks += 4) {
+      const bf16x8 fa = *(const bf16x8*)(ha + ks * 64);
+      const bf16x8 fb = *(const bf16x8*)(ab + ks * 64);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) part[((wave - 1) * 64 + lane) * 4 + j] = acc[j];
+      for (int j = 0; j < 4; ++j) part[((wave - 1) * 64 + lane) * 4 + j] = acc[j];
+    }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the partial blocks are in LDS
-  __builtin_amdgcn_s_barrier();         // (waves 4..15 have left: the barrier counts the four that remain)
+  __syncthreads();                      // the partial blocks of waves 1..3 are in LDS
   // C/D layout of the 16x16 MFMA: col = lane & 15 (adapter column), row = (lane >> 4) * 4 + reg (token)
   if (wave == 0 && r16 < R2) {
 #pragma unroll

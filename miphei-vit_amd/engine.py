@@ -839,6 +839,7 @@ class HipEngine:
         """WeightedMSELoss value (device scalar, f64) and dL/d(out) in the workspace."""
         w = self._saved.w
         w.scal.zero_()
+        w.sqn_fresh = True
         ops.wmse_fwd_bwd(out, target.to(torch.float32).contiguous(), marker_weights, w.loss_acc, w.dY, float(lambda_factor))
         B, C, H, W = out.shape
         return w.loss_acc * (float(lambda_factor) / (C * B * H * W)), w.dY
@@ -848,7 +849,12 @@ class HipEngine:
         if fl.m is None:
             fl.m, fl.v = torch.zeros_like(fl.flat), torch.zeros_like(fl.flat)
         fl.step += 1
-        ops.sqnorm(fl.gflat, w.sqn)       # (w.sqn was zeroed with the loss accumulator in loss_and_grad)
+        # the square-norm accumulator is zeroed by loss_and_grad (one fill for loss + norm); a caller that reaches adam_step
+        # without it (external dY, custom loss, a second adam_step) gets its own fill, so the norm never accumulates across steps
+        if not getattr(w, "sqn_fresh", False):
+            w.sqn.zero_()
+        w.sqn_fresh = False
+        ops.sqnorm(fl.gflat, w.sqn)
         ops.adam_clip_step(fl.flat, fl.gflat, fl.m, fl.v, w.sqn, float(lr), betas[0], betas[1], eps,
                            1.0 - betas[0] ** fl.step, 1.0 - betas[1] ** fl.step, float(max_norm),
                            nonfinite=self.nonfinite_flag())

@@ -105,6 +105,7 @@ class UnetrEngine:
     def loss_and_grad(self, out, target, marker_weights, lambda_factor):
         w = self._saved.w
         w.scal.zero_()
+        w.sqn_fresh = True
         ops.wmse_fwd_bwd(out, target.to(torch.float32).contiguous(), marker_weights, w.loss_acc, w.dY, float(lambda_factor))
         B, C, H, W = out.shape
         return w.loss_acc * (float(lambda_factor) / (C * B * H * W)), w.dY
@@ -123,7 +124,10 @@ class UnetrEngine:
             if f.m is None:
                 f.m, f.v = torch.zeros_like(f.flat), torch.zeros_like(f.flat)
             f.step += 1
-        ops.sqnorm(fl.gflat, w.sqn)           # one global norm over both buffers (w.sqn was zeroed in loss_and_grad)
+        if not getattr(w, "sqn_fresh", False):   # zeroed with the loss accumulator by loss_and_grad; any other caller: own fill
+            w.sqn.zero_()
+        w.sqn_fresh = False
+        ops.sqnorm(fl.gflat, w.sqn)           # one global norm over both buffers
         ops.sqnorm(efl.gflat, w.sqn)
         for f in (fl, efl):
             ops.adam_clip_step(f.flat, f.gflat, f.m, f.v, w.sqn, float(lr), betas[0], betas[1], eps, 1.0 - betas[0] ** f.step,

@@ -174,12 +174,22 @@ class ModelModule(_Base):
             ev.synchronize()
             if int(host) != 0:
                 self._pending = []
-                torch.save(self.checkpoint_state(), "weights_nan.ckpt")   # the update was gated: last finite weights
+                self._dump_nan_weights(self.checkpoint_state())           # the update was gated: last finite weights
                 raise ValueError("Nan found")
         if flag is None and loss is not None and self.nan_check:   # generators without the fused step: the reference's sync check
             if not bool(torch.isfinite(loss)):
-                torch.save(self.state_dict(), "weights_nan.ckpt")
+                self._dump_nan_weights(self.state_dict())
                 raise ValueError("Nan found")
+
+    @staticmethod
+    def _dump_nan_weights(state):
+        """``weights_nan.ckpt`` (reference models.py:103-104), written by rank 0 only: data-parallel replicas hold identical
+        parameters, and every rank writing the same path at once would corrupt the file."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return
+        from .checkpoint import save_checkpoint_atomic
+        save_checkpoint_atomic(state, "weights_nan.ckpt")
 
     def on_train_end(self):
         self._nan_guard(flush=True)
@@ -203,8 +213,17 @@ class ModelModule(_Base):
         sd = {k[len("generator."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("generator.")}
         self.generator.load_state_dict(sd)
         self.global_step_ = int(ckpt.get("global_step", 0))
-        if ckpt.get("total_iters") is not None:
-            self.total_iters = ckpt["total_iters"]
+        # LR horizon: a horizon configured on this module BEFORE loading (run.py sets total_iters = train.max_steps) wins, as
+        # Lightning / LambdaLR rebuild the lambda from the new trainer's horizon when a run is resumed with more steps; the
+        # checkpoint's value is only adopted when none is configured.  A silent restore of the old horizon would clamp the
+        # pix2pix ramp to lr = 0 for every step past it.
+        saved = ckpt.get("total_iters")
+        if self.total_iters is None:
+            self.total_iters = saved
+        elif saved is not None and int(saved) != int(self.total_iters):
+            import warnings
+            warnings.warn(f"resuming at step {self.global_step_} with LR horizon {int(self.total_iters)} steps (the checkpoint "
+                          f"was written with {int(saved)}): the pix2pix schedule follows the NEW horizon", stacklevel=2)
         eng = getattr(self.generator, "_engine", None)
         if eng is not None and hasattr(eng, "load_optimizer_state_dict"):
             eng.load_optimizer_state_dict(ckpt.get("optimizer_state"))

@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT)
 
 
 def main(argv):
-    from bench import synthetic_batch, synthetic_init_
-    from miphei_vit_amd.checkpoint import save_pruned_safetensors
+    from miphei_vit_amd.synthetic import synthetic_batch, synthetic_init_
+    from miphei_vit_amd.checkpoint import save_checkpoint_atomic, save_pruned_safetensors
     from miphei_vit_amd.config import compose
     from miphei_vit_amd.generators import get_generator
     from miphei_vit_amd.loss import WeightedMSELoss, marker_weights_from_file
@@ -28,12 +28,32 @@ def main(argv):
     from miphei_vit_amd.trainer import DataParallelSync
 
     cfg = compose(os.path.join(ROOT, "configs"), argv)
+    # Config branches of the reference's train.py that switch the objective (src/train.py:118-150) and are NOT on this path
+    # fail loudly instead of silently training with WeightedMSELoss
+    losses = cfg.train.losses
+    if losses.get("use_weighted_mae"):
+        raise NotImplementedError("train.losses.use_weighted_mae: the foreground-weighted focal loss (reference src/train.py:"
+                                  "118-132) is outside the MI355X hot path; WeightedMSELoss (use_weighted_mae: false) is")
+    if (losses.get("cell_loss") or {}).get("use_loss"):
+        raise NotImplementedError("train.losses.cell_loss.use_loss: the cell-level loss (reference src/train.py:144-150) is "
+                                  "outside the MI355X hot path")
+    if cfg.train.get("use_cell_metrics"):
+        raise NotImplementedError("train.use_cell_metrics: validation-time CellMetrics are not wired into run.py "
+                                  "(miphei_vit_amd.cells has the extractor); set ++train.use_cell_metrics=false")
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    # MIPHEI_DIST_BACKEND=gloo MIPHEI_SHARE_GPU=1: rehearsal of the multi-rank branch on a one-GPU box (RCCL refuses two ranks
+    # on one device; gloo takes device tensors): every rank uses cuda:0.  The product transport is RCCL ("nccl").
+    backend = os.environ.get("MIPHEI_DIST_BACKEND", "nccl")
+    if os.environ.get("MIPHEI_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     nc = len(cfg.data.targ_channel_names)
     S, B = int(cfg.data.tile_size), int(cfg.train.batch_size)
     with torch.device(dev):
@@ -58,10 +78,11 @@ def main(argv):
     start = 0
     resume = cfg.train.get("resume_from")
     if resume:      # ++train.resume_from=logs/last.ckpt : weights, Adam moments + step count, LR-schedule position
-        module.load_checkpoint_state(torch.load(resume, map_location="cpu", weights_only=False))
+        # plain tensors / dicts / scalars only: safe to load with weights_only=True
+        module.load_checkpoint_state(torch.load(resume, map_location="cpu", weights_only=True))
         start = module.global_step_
         if rank == 0:
-            print(f"resumed from {resume} at step {start}", flush=True)
+            print(f"resumed from {resume} at step {start} (LR horizon {module.total_iters} steps)", flush=True)
     every = int(cfg.train.get("checkpoint_every") or 0)
     t0 = time.perf_counter()
     for i in range(start, steps):
@@ -72,13 +93,13 @@ def main(argv):
         if rank == 0 and every and (i + 1) % every == 0 and i + 1 < steps:
             # rank 0's replica: parameters are identical on all ranks, BatchNorm running statistics are rank-local (noted in
             # the file as "bn_running_stats": "rank-local")
-            torch.save(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
+            save_checkpoint_atomic(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
     module.on_train_end()           # drains the asynchronous NaN guard
     torch.cuda.synchronize()
     if rank == 0:
         dt = time.perf_counter() - t0
         print(f"{steps - start} steps, {world * B * (steps - start) / dt:.1f} tiles/s")
-        torch.save(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
+        save_checkpoint_atomic(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
         save_pruned_safetensors(generator, os.path.join(logdir, "model.safetensors"))
         print("saved", os.path.join(logdir, "model.safetensors"))
     if dist.is_initialized():

@@ -32,7 +32,7 @@ def main():
     from miphei_vit_amd.config import compose
     from miphei_vit_amd.generators import get_generator
     from miphei_vit_amd.io_stage import InputStage, export_uint8
-    from bench import synthetic_init_
+    from miphei_vit_amd.synthetic import synthetic_init_
 
     cfg = compose(os.path.join(ROOT, "configs"), overrides)
     dev = torch.device("cuda", 0)

@@ -67,9 +67,35 @@ def test_cell_means_full_tile_against_oracle(scale):
     assert np.allclose(pm.cpu().numpy(), rp, atol=2e-5) and np.allclose(tm.cpu().numpy(), rt, atol=2e-5)
 
 
-def test_cell_extractor_reports_scratch_overflow():
+def test_cell_extractor_dense_label_maps_retry_and_chunk():
+    """More (tile, nucleus) fragments than the scratch holds: the reference (unique + scatter_add) has no such limit, so the
+    wrapper retries with the larger scratch and then on row chunks whose partial sums are merged per nucleus."""
+    from oracle.cells import extract_means
     from miphei_vit_amd.cells import MeanCellExtrator
+    rng = np.random.default_rng(7)
     S = 256
-    lab = (1 + torch.arange(S * S).view(1, S, S)).cuda()         # every pixel its own nucleus: 65536 records > capacity
-    with pytest.raises(RuntimeError, match="exceed the scratch capacity"):
-        MeanCellExtrator()(torch.zeros(1, 2, S, S).cuda(), None, lab)
+    pred = rng.standard_normal((2, 3, S, S), dtype=np.float32)
+    target = rng.standard_normal((2, 3, S, S), dtype=np.float32)
+    lab = np.zeros((2, S, S), dtype=np.int64)
+    lab[0] = 1 + np.arange(S * S).reshape(S, S)                    # every pixel its own nucleus: 65536 records (chunked path)
+    yy, xx = np.mgrid[0:S, 0:S]
+    lab[1] = 7 + (yy // 2) * (S // 2) + xx // 2                    # 2x2 blocks spanning chunk boundaries never; 16384 nuclei
+    lab[1, :, 100:140] = 3                                         # one nucleus crossing every row chunk: partials must merge
+    pm, tm, ids = MeanCellExtrator()(torch.from_numpy(pred).cuda(), torch.from_numpy(target).cuda(), torch.from_numpy(lab).cuda())
+    rp, rt, ri, _ = extract_means(pred, target, lab, 1.0)
+    assert np.array_equal(ids.cpu().numpy(), ri)
+    assert np.allclose(pm.cpu().numpy(), rp, atol=2e-5) and np.allclose(tm.cpu().numpy(), rt, atol=2e-5)
+    # 12288 records: fits the second scratch size without chunking
+    lab2 = np.zeros((1, S, S), dtype=np.int64)
+    lab2[0, :48] = 1 + np.arange(48 * S).reshape(48, S)
+    pm, _, ids = MeanCellExtrator()(torch.from_numpy(pred[:1]).cuda(), None, torch.from_numpy(lab2).cuda())
+    rp, _, ri, _ = extract_means(pred[:1], None, lab2, 1.0)
+    assert np.array_equal(ids.cpu().numpy(), ri) and np.allclose(pm.cpu().numpy(), rp, atol=2e-5)
+
+
+def test_cell_extractor_rejects_ids_beyond_int32():
+    from miphei_vit_amd.cells import MeanCellExtrator
+    lab = torch.zeros(1, 128, 128, dtype=torch.int64)
+    lab[0, 3, 3] = 2 ** 31 + 5
+    with pytest.raises(ValueError, match="INT32_MAX"):
+        MeanCellExtrator()(torch.zeros(1, 2, 128, 128).cuda(), None, lab.cuda())

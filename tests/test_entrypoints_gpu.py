@@ -29,7 +29,7 @@ def test_run_train_resume_and_inference_tiny_recipe():
     common = ["+default_configs=tiny", "++data.tile_size=128", "++train.batch_size=2"]
     p = _run(["run.py"] + common + ["++train.max_steps=6", "++train.checkpoint_every=3"])
     assert "step     0" in p.stdout and "tiles/s" in p.stdout
-    ck = torch.load(os.path.join(logs, "last.ckpt"), map_location="cpu", weights_only=False)
+    ck = torch.load(os.path.join(logs, "last.ckpt"), map_location="cpu", weights_only=True)
     assert ck["global_step"] == 6 and ck["optimizer_state"]["step"] == 6 and ck["bn_running_stats"] == "rank-local"
     assert any(k.startswith("generator.decoder.") for k in ck["state_dict"]) and "loss_reconstruct.marker_weights" in ck["state_dict"]
     from safetensors.torch import load_file
@@ -54,3 +54,22 @@ def test_run_unetr_recipe_with_shipped_dropout():
     assert "step     3" in p.stdout
     losses = [float(l.split("loss")[1].split()[0]) for l in p.stdout.splitlines() if l.startswith("step")]
     assert all(np.isfinite(losses))
+
+
+def test_run_py_two_ranks_rehearsal_on_one_gpu():
+    """The multi-rank branch of run.py (rendezvous, parameter broadcast, bucketed exchange inside training_step, rank-0 checkpoint
+    writes): two ranks share cuda:0 and exchange over gloo -- RCCL refuses two ranks on one device, the transport is the only
+    difference to the 8-GPU command line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MIPHEI_DIST_BACKEND="gloo", MIPHEI_SHARE_GPU="1", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "run.py", "+default_configs=tiny", "++data.tile_size=128",
+                        "++train.batch_size=2", "++train.max_steps=4", "++train.checkpoint_every=2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert p.stdout.count("step     0") == 1 and "tiles/s" in p.stdout          # rank 0 alone reports
+    ck = torch.load(os.path.join(ROOT, "logs", "last.ckpt"), map_location="cpu", weights_only=True)
+    assert ck["global_step"] == 4

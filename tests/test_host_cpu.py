@@ -263,3 +263,53 @@ def test_bench_parent_does_not_touch_the_gpu_before_launching():
     main = src[src.index("def main("):]
     assert main.index("self_launch(a, argv)") < main.index("torch.cuda.")
     assert "os.exec" not in src and "execv" not in src
+
+
+def test_resume_keeps_the_configured_lr_horizon(tmp_path):
+    """Resuming with a larger train.max_steps extends training: the horizon configured on the module before the load wins (as
+    Lightning / LambdaLR rebuild the lambda from the new trainer), the checkpoint's one is adopted only when none is set."""
+    import warnings
+    from miphei_vit_amd.checkpoint import save_checkpoint_atomic
+    from miphei_vit_amd.loss import WeightedMSELoss
+    from miphei_vit_amd.models import ModelModule
+    mk = lambda: ModelModule(torch.nn.Linear(3, 3), None, 1e-3, 0., WeightedMSELoss(50.0, torch.ones(3)))
+    a = mk()
+    a.total_iters, a.global_step_ = 1000, 900
+    path = save_checkpoint_atomic(a.checkpoint_state(), tmp_path / "last.ckpt")
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    ck = torch.load(path, map_location="cpu", weights_only=True)          # plain tensors / dicts: loads in the safe mode
+    b = mk()
+    b.total_iters = 4000                                                   # run.py: module.total_iters = train.max_steps
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        b.load_checkpoint_state(ck)
+    assert b.global_step_ == 900 and b.total_iters == 4000 and any("horizon" in str(x.message) for x in w)
+    assert b.current_lr() == pytest.approx(1e-3)                           # step 900 of 4000: plateau (old horizon: 0.2e-3)
+    assert b.current_lr(3000) == pytest.approx(0.5e-3)
+    c = mk()
+    c.load_checkpoint_state(ck)                                            # nothing configured: the saved horizon is adopted
+    assert c.total_iters == 1000 and c.current_lr() == pytest.approx(0.2e-3)
+    # an interrupted write leaves the previous checkpoint in place
+    class Boom:
+        def __reduce__(self):
+            raise RuntimeError("disk full")
+    with pytest.raises(RuntimeError):
+        save_checkpoint_atomic({"x": Boom()}, path)
+    assert torch.load(path, map_location="cpu", weights_only=True)["global_step"] == 900
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+
+
+@pytest.mark.parametrize("override,needle", [("++train.losses.use_weighted_mae=true", "use_weighted_mae"),
+                                             ("++train.losses.cell_loss.use_loss=true", "cell_loss"),
+                                             ("++train.use_cell_metrics=true", "use_cell_metrics")])
+def test_run_py_refuses_objectives_outside_the_path(override, needle):
+    """reference src/train.py:118-150 switches the loss on these keys; run.py must not silently train with WeightedMSELoss"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "run.py"), "+default_configs=tiny", override], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert p.returncode != 0 and "NotImplementedError" in p.stderr and needle in p.stderr, p.stderr[-2000:]
+
+
+def test_entry_points_do_not_depend_on_the_benchmark_script():
+    for f in ("run.py", "run_inference.py"):
+        src = open(os.path.join(ROOT, f)).read()
+        assert "from bench" not in src and "import bench" not in src, f
