@@ -38,7 +38,7 @@ enum mvit_epilogue {
   MVIT_EPI_DGELU = 7     /* C = acc * gelu'(aux)                                             */
 };
 enum mvit_gemm_flags { MVIT_OUT_F32 = 1, MVIT_ATOMIC = 2 /* f32 atomicAdd (split-K) */, MVIT_ACCUM_BF16 = 4 /* C(bf16) += */ };
-enum mvit_amode { MVIT_A_DENSE = 0, MVIT_A_CONV3 = 1, MVIT_A_CONV3_T = 2 };
+enum mvit_amode { MVIT_A_DENSE = 0, MVIT_A_CONV3 = 1, MVIT_A_CONV3_T = 2, MVIT_A_PATCH = 3 };
 
 /*
  * C[M,N] = A[M,K] * B[N,K]^T (+ A2[M,K2] * B2[N,K2]^T), bf16 operands, f32 accumulate on MFMA.
@@ -47,6 +47,11 @@ enum mvit_amode { MVIT_A_DENSE = 0, MVIT_A_CONV3 = 1, MVIT_A_CONV3_T = 2 };
  *   virtual im2col matrix gathers the 3x3 window (pad 1, stride conv_stride), k=(ky,kx,c), K=9*conv_C.
  * amode CONV3_T: the adjoint gather (dgrad): rows m index the conv *input* grid [B,conv_OH,conv_OW],
  *   A is dY [B, conv_H, conv_W, conv_ld].
+ * amode PATCH: the patch-embedding convolution (kernel = stride = conv_stride, timm PatchEmbed.proj built at
+ *   src/generators/foundation_models.py:53-57) as an in-kernel window gather: A is the bf16 NHWC image [B, conv_H, conv_W, 8]
+ *   (3 colour channels + 5 zeros: one 16-byte piece per pixel, the decoder's image operand), row m = (b, py, px) of the
+ *   conv_OH x conv_OW patch grid, k = (dy * conv_stride + dx) * 8 + c, K = conv_stride^2 * 8; pixels beyond the last whole
+ *   patch are ignored; epilogue EPI_PATCH only.  No im2col buffer exists.
  * Replaces: every nn.Linear of the timm ViT built at src/generators/foundation_models.py:53-57,
  *   LoRA (src/generators/lora.py:16-18,29-33), nn.Conv2d in Basic_Conv3x3 (src/generators/mipheivit.py:32)
  *   and Fusion_Block (mipheivit.py:86), and their autograd backward (src/models.py:135).
@@ -94,6 +99,10 @@ typedef struct mvit_gemm_tn_args {
    * ViT blocks, whose per-block launches (4 steps of m each) are latency-bound. */
   int batch;
   long long strideA, strideB, strideC;
+  /* split_stride > 0: slice z of the m range accumulates into C + z * split_stride (and C2 + z * split_stride) instead of
+   * sharing C through f32 atomics: one contributing block per element, the caller adds the msplit copies in a fixed order
+   * (the deterministic mode of the host, MIPHEI_DETERMINISTIC=1); 0 = shared output */
+  long long split_stride;
 } mvit_gemm_tn_args;
 MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_stream_t stream);
 
@@ -122,8 +131,6 @@ MVIT_API int mvit_skinny_xw(const void* X, int ldx, const void* W, int ldw, void
 /* two such products of one shape in one launch (the q and v adapters' dt = dq @ B_q^T, dv @ B_v^T) */
 MVIT_API int mvit_skinny_xw2(const void* X0, const void* W0, void* out0, const void* X1, const void* W1, void* out1, int ldx,
                              int ldw, int ldo, int M, int K, int R, mvit_stream_t stream);
-/* NCHW f32 image -> bf16 patch matrix [B*g*g, Kp], k = c*p*p + iy*p + ix (timm PatchEmbed conv k=s=p). */
-MVIT_API int mvit_im2col_patch(const float* img, void* out_bf16, int B, int S, int p, int g, int Kp, mvit_stream_t stream);
 /* x[b,0]=cls, x[b,1..R]=reg  (timm _pos_embed with no_embed_class=True). */
 MVIT_API int mvit_prefix_tokens(float* x, const float* cls, const float* reg, int B, int ntok, int D, int R,
                                 mvit_stream_t stream);
@@ -310,6 +317,21 @@ MVIT_API int mvit_adam_clip_step(float* p, const float* g, float* m, float* v, c
  * ToTensor; with scale = 1.8/255, shift = -0.9 the target transform (dataset.py:573).  HW % 4 == 0. */
 MVIT_API int mvit_u8_nhwc_to_f32_nchw(const void* src_u8, float* dst, const float* scale, const float* shift, int B, int C,
                                       long long HW, mvit_stream_t stream);
+/* Training-time spatial augmentation + normalisation of a batch of uint8 tiles, jointly for the H&E image [B,Hs,Ws,3] and the mIF
+ * target [B,Hs,Ws,C] (either may be NULL): RandomCrop(H, W) -> HorizontalFlip(p_hflip) -> VerticalFlip(p_vflip) ->
+ * CoarseDropout(p_drop, one hole, height / width uniform integers in [0, hole_frac * size], fill 0), the Compose of
+ * src/dataset.py:458-468 with additional_targets={'image_target': 'image'} (same draw for both).  Outputs: out_img f32 NCHW
+ * (px - mean) / std (NormalizationLayer "he", dataset.py:570), out_tgt f32 NCHW px / 255 * 1.8 - 0.9 (dataset.py:573) with the
+ * reference's f32 operation order (bit-identical to the numpy expressions), out_nhwc8 (optional) bf16 [B,H,W,8] = the engine's
+ * decoder image buffer (channels 3..7 zero).  Draws are counter-based: splitmix64(seed + golden * (16 * (sample0 + b) + k + 1)),
+ * k = 0..8 -> crop y, crop x, hflip, vflip, dropout, hole h, hole w, hole y, hole x; mvit_augment_draw recomputes them on the
+ * host.  W % 4 == 0. */
+MVIT_API int mvit_augment_tiles(const void* img_u8, const void* tgt_u8, float* out_img, float* out_tgt, void* out_nhwc8, int B,
+                                int C, int Hs, int Ws, int H, int W, unsigned long long seed, unsigned long long sample0,
+                                float p_hflip, float p_vflip, float p_drop, float hole_frac, const float* mean3,
+                                const float* std3, mvit_stream_t stream);
+MVIT_API int mvit_augment_draw(int Hs, int Ws, int H, int W, unsigned long long seed, unsigned long long sample, float p_hflip,
+                               float p_vflip, float p_drop, float hole_frac, int* out9);
 /* dst(u8)[i] = trunc(clamp((src[i]+0.9)/1.8, 0, 1) * 255): SavePredictionsCallback, src/callbacks.py:345-346.  n % 4 == 0. */
 MVIT_API int mvit_f32_to_u8_export(const float* src, void* dst_u8, long long n, mvit_stream_t stream);
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmiphei_hip.so")
 # enum mvit_epilogue
 EPI_STORE, EPI_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_STATS, EPI_DSWIGLU, EPI_DGELU = range(8)
 OUT_F32, ATOMIC, ACCUM_BF16 = 1, 2, 4
-A_DENSE, A_CONV3, A_CONV3_T = 0, 1, 2
+A_DENSE, A_CONV3, A_CONV3_T, A_PATCH = 0, 1, 2, 3
 
 vp, ci, cf, cd, ll = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong
 
@@ -37,7 +37,7 @@ class GemmTnArgs(C.Structure):
                 ("M", ci), ("I", ci), ("J", ci), ("lda", ci), ("ldb", ci), ("amode", ci), ("msplit", ci),
                 ("conv_H", ci), ("conv_W", ci), ("conv_C", ci), ("conv_ld", ci), ("conv_OH", ci), ("conv_OW", ci),
                 ("conv_stride", ci), ("C2", vp), ("isplit", ci), ("j1", ci), ("jlo2", ci), ("batch", ci),
-                ("strideA", ll), ("strideB", ll), ("strideC", ll)]
+                ("strideA", ll), ("strideB", ll), ("strideC", ll), ("split_stride", ll)]
 
 
 class ConvPackDesc(C.Structure):
@@ -64,7 +64,6 @@ SIGNATURES = {
     "mvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp],
     "mvit_skinny_xw": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
     "mvit_skinny_xw2": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
-    "mvit_im2col_patch": [vp, vp, ci, ci, ci, ci, ci, vp],
     "mvit_prefix_tokens": [vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_cast_f32_bf16": [vp, vp, C.c_longlong, vp],
     "mvit_scale_cols_cast": [vp, vp, vp, ci, ci, vp, vp],
@@ -97,6 +96,8 @@ SIGNATURES = {
     "mvit_sqnorm": [vp, vp, ll, vp],
     "mvit_u8_nhwc_to_f32_nchw": [vp, vp, vp, vp, ci, ci, ll, vp],
     "mvit_f32_to_u8_export": [vp, vp, ll, vp],
+    "mvit_augment_tiles": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, C.c_ulonglong, C.c_ulonglong, cf, cf, cf, cf, vp, vp, vp],
+    "mvit_augment_draw": [ci, ci, ci, ci, C.c_ulonglong, C.c_ulonglong, cf, cf, cf, cf, vp],
     "mvit_cell_means": [vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mvit_adam_clip_step": [vp, vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, cf, vp, vp],
 }

@@ -325,9 +325,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* _
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  double* __restrict__ stats, long long M, int C, int nslots,
                                                                  DropCfg drop) {
-  __shared__ float red[2 * 512];
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  // per-thread partial sums meet in a FIXED order (no LDS atomics): part[row group][2C], then one thread per statistic adds the
+  // row groups in ascending order -> the block's contribution does not depend on wave scheduling
+  __shared__ float part[256 * 16];
   const int cv = C >> 3;
   const int c8 = threadIdx.x % cv, rl = threadIdx.x / cv, rpb = 256 / cv;
   float s1[8], s2[8], sc[8], sh[8], mu[8], rs[8];
@@ -351,13 +351,18 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* _
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      atomicAdd(&red[c8 * 8 + j], s1[j]);
-      atomicAdd(&red[C + c8 * 8 + j], s2[j]);
+      part[rl * 2 * C + c8 * 8 + j] = s1[j];
+      part[rl * 2 * C + C + c8 * 8 + j] = s2[j];
     }
   }
   __syncthreads();
+  // one writer block per slot when nslots >= gridDim.x (the deterministic configuration); otherwise slots are shared
   double* st = stats + (size_t)(blockIdx.x % nslots) * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(st + i, (double)red[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rpb; ++r) t += part[r * 2 * C + i];
+    atomicAdd(st + i, (double)t);
+  }
 }
 
 // apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); block 0 also emits dgamma += s2, dbeta += s1
@@ -583,7 +588,8 @@ MVIT_API int mvit_bn_relu_bwd_reduce(const void* dy, int ld_dy, const void* x, c
   MVIT_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return MVIT_EINVAL;
   const int rpb = 256 / (C >> 3);
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk(M, rpb * 16, 2048)), dim3(256), 0, (hipStream_t)stream,
+  // (>= 256 slots: the grid is capped at the slot count, one writer block per slot -> run-to-run identical statistics)
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(nblk(M, rpb * 16, nslots >= 256 ? nslots : 2048)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, stats, M, C, nslots,
                      make_drop(drop_p, drop_seed));
   return MVIT_LAUNCH_CHECK();

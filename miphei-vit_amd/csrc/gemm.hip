@@ -16,7 +16,13 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MVIT_EINVAL;
   if ((a.K & 7) || (a.ldb & 7)) return MVIT_EINVAL;
   if (a.amode == MVIT_A_DENSE && (a.lda & 7)) return MVIT_EINVAL;
-  if (a.amode != MVIT_A_DENSE && ((a.conv_C & 7) || (a.conv_ld & 7) || a.K != 9 * a.conv_C || a.A2)) return MVIT_EINVAL;
+  if (a.amode == MVIT_A_PATCH) {
+    if (a.conv_C != 8 || a.conv_ld != 8 || a.conv_stride <= 0 || a.K != a.conv_stride * a.conv_stride * 8 || a.A2 ||
+        a.epi != MVIT_EPI_PATCH || a.conv_OH * a.conv_stride > a.conv_H || a.conv_OW * a.conv_stride > a.conv_W)
+      return MVIT_EINVAL;
+  } else if (a.amode != MVIT_A_DENSE && ((a.conv_C & 7) || (a.conv_ld & 7) || a.K != 9 * a.conv_C || a.A2)) {
+    return MVIT_EINVAL;
+  }
   if (a.A2 && ((a.K2 & 7) || (a.lda2 & 7) || (a.ldb2 & 7) || !a.B2)) return MVIT_EINVAL;
   if (a.ksplit > 1 && !(a.flags & MVIT_ATOMIC)) return MVIT_EINVAL;
   if (a.epi == MVIT_EPI_STATS && (!a.stats || a.nslots <= 0)) return MVIT_EINVAL;
@@ -26,7 +32,7 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   mvit_gemm_args al = a;  // vector (8/16-byte) epilogue I/O needs aligned pointers and leading dimensions
   {
     auto mis = [](const void* q, int ld) { return q && ((((uintptr_t)q) & 15) || (ld & 7)); };
-    if (mis(a.C, a.ldc) || mis(a.aux, a.ldaux) || mis(a.bias, 0) || mis(a.gamma, 0)) al.flags |= 0x400;
+    if (mis(a.C, a.ldc) || mis(a.aux, a.ldaux) || mis(a.bias, 0) || mis(a.gamma, 0) || mis(a.pos, a.N)) al.flags |= 0x400;
     if (a.epi == MVIT_EPI_SWIGLU && (a.ldc & 7)) al.flags |= 0x400;
   }
   return dispatch(al, s);

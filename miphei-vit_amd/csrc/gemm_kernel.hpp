@@ -169,6 +169,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         const int t = g / p.conv_OW;
         crow[j].y = t % p.conv_OH;
         crow[j].b = t / p.conv_OH;
+        if (AMODE == MVIT_A_PATCH) {   // row = (image, patch row, patch column): keep the window's first pixel
+          crow[j].y *= p.conv_stride;
+          crow[j].x *= p.conv_stride;
+        }
       }
     }
   };
@@ -193,6 +197,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * RPI * 128), 16, off, 0, 0, 0);
         else
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, 0, 0, 0);
+      }
+    } else if constexpr (AMODE == MVIT_A_PATCH) {
+      // non-overlapping patch windows (patch-embed convolution, kernel = stride = conv_stride) of an NHWC bf16 image whose pixels
+      // are one 16-byte piece (conv_ld = 8 channels, the unused ones zero): k = (dy * patch + dx) * 8 + c, so the piece of this
+      // lane's K slot is pixel (dy, dx) of the window; rows of the image beyond the last whole patch are never addressed
+      const int q = k0 >> 3;
+      const int dy = q / p.conv_stride, dx = q - dy * p.conv_stride;
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        const bool ok = kok && crow[j].ok;
+        const unsigned lin =
+            (((unsigned)(crow[j].b * p.conv_H + crow[j].y + dy) * (unsigned)p.conv_W + (unsigned)(crow[j].x + dx)) * (unsigned)p.conv_ld) * 2u;
+        unsigned off = ok ? lin : OOB;
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * RPI * 128), 16, off, 0, 0, 0);
       }
     } else {
       const int tap = k0 / p.conv_C, ch = k0 - tap * p.conv_C;
@@ -889,7 +908,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
               } else if constexpr (EPI == MVIT_EPI_PATCH) {
                 const int img = row / p.patch_P, pp = row - img * p.patch_P;
                 const size_t o = (size_t)(img * p.patch_ntok + p.patch_prefix + pp) * p.ldc + col;
-                for (int e = 0; e < nv; ++e) Cf[o + e] = v[e] + p.pos[(size_t)pp * p.N + col + e];
+                float pe[V];
+                ld8f(p.pos + (size_t)pp * p.N + col, pe, nv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] += pe[e];
+                st8f(Cf + o, v, nv);
               } else if constexpr (EPI == MVIT_EPI_STATS) {
                 st8bf(Cb + (size_t)row * p.ldc + col, v, nv);
 #pragma unroll
@@ -954,7 +977,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           s_ += red[(w * BN + tid) * 2 + 0];
           q_ += red[(w * BN + tid) * 2 + 1];
         }
-        double* st = p.stats + (size_t)((blockIdx.x + vt) % p.nslots) * 2 * p.N;
+        // slot: one writer block per slot when the caller provides at least gridDim.x slots (sums are then added in program
+        // order only: run-to-run identical statistics); otherwise slots are shared and merely spread the atomic traffic
+        double* st = p.stats + (size_t)(p.nslots >= (int)gridDim.x ? (int)blockIdx.x : (int)((blockIdx.x + vt) % p.nslots)) * 2 * p.N;
         atomicAdd(st + en0 + tid, s_);
         atomicAdd(st + p.N + en0 + tid, q_);
       }
@@ -975,6 +1000,7 @@ int launch_one(const mvit_gemm_args& a, hipStream_t s) {
   per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   int gx = gemm_num_cus() * per_cu;
   if (gx > tiles) gx = tiles;
+  if (EPI == MVIT_EPI_STATS && a.nslots >= 256 && gx > a.nslots) gx = a.nslots;   // (>= 256 slots: one writer per slot, see the epilogue)
   dim3 grid(gx, 1, a.ksplit > 1 ? a.ksplit : 1);
   auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
   static mvit_per_device_size raised;  // per instantiation, per device
@@ -1012,6 +1038,8 @@ int launch_conv(const mvit_gemm_args& a, hipStream_t s);
       if (a.epi == MVIT_EPI_STORE) return launch_one<BM, BN, WM, WN, MVIT_A_CONV3, MVIT_EPI_STORE>(a, s); \
     } else if (a.amode == MVIT_A_CONV3_T) {                                                       \
       if (a.epi == MVIT_EPI_STORE) return launch_one<BM, BN, WM, WN, MVIT_A_CONV3_T, MVIT_EPI_STORE>(a, s); \
+    } else if (a.amode == MVIT_A_PATCH) {                                                         \
+      if (a.epi == MVIT_EPI_PATCH) return launch_one<BM, BN, WM, WN, MVIT_A_PATCH, MVIT_EPI_PATCH>(a, s); \
     }                                                                                             \
     return MVIT_EINVAL;                                                                           \
   }

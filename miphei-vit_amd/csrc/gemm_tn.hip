@@ -146,8 +146,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
     cur ^= 1;
   }
   // D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*half
-  float* C = (float*)p.C + (size_t)bi * p.strideC;
-  float* C2 = p.C2 ? p.C2 + (size_t)bi * p.strideC : nullptr;
+  // split_stride > 0: slice zi of the m range adds into its own copy of the output (C + zi * split_stride) -- every element
+  // then has exactly one contributing block and the caller sums the copies in a fixed order (run-to-run identical results)
+  float* C = (float*)p.C + (size_t)bi * p.strideC + (size_t)zi * p.split_stride;
+  float* C2 = p.C2 ? p.C2 + (size_t)bi * p.strideC + (size_t)zi * p.split_stride : nullptr;
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int j = j0 + wave_j * WJT + t * 32 + l31;
@@ -191,6 +193,7 @@ extern "C" MVIT_API int mvit_gemm_tn_bf16(const mvit_gemm_tn_args* args, mvit_st
   const mvit_gemm_tn_args& a = *args;
   if (a.M <= 0 || a.I <= 0 || a.J <= 0 || (a.I & 7) || (a.J & 7) || (a.ldb & 7)) return MVIT_EINVAL;
   if (a.C2 && (a.isplit <= 0 || a.isplit >= a.I || a.jlo2 < 0 || (a.jlo2 > 0 && (a.j1 <= 0 || a.j1 > a.jlo2)))) return MVIT_EINVAL;
+  if (a.split_stride < 0) return MVIT_EINVAL;
   if (a.batch < 0 || (a.batch > 1 && (a.amode != MVIT_A_DENSE || ((a.strideA | a.strideB) & 7)))) return MVIT_EINVAL;
   if (a.amode == MVIT_A_DENSE) {
     if (a.lda & 7) return MVIT_EINVAL;

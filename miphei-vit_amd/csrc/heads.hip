@@ -170,12 +170,17 @@ __global__ __launch_bounds__(256) void moments_kernel(const bf16_t* __restrict__
     s = mfma(f1, ones.v, s);
     __builtin_amdgcn_wave_barrier();
   }
+  // the four waves add their partial moments in wave order (no LDS atomics: the block's sum is independent of scheduling)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    atomicAdd(&red[XC + acc_row(j, half) * XC + l31], acc[j]);
-    if (l31 == 0) atomicAdd(&red[acc_row(j, half)], s[j]);
+      for (int j = 0; j < 16; ++j) {
+        red[XC + acc_row(j, half) * XC + l31] += acc[j];
+        if (l31 == 0) red[acc_row(j, half)] += s[j];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   double* o = mom + (size_t)(blockIdx.x % nslots) * NMOM;
   for (int e = threadIdx.x; e < NMOM; e += 256) atomicAdd(o + e, (double)red[e]);
 }
@@ -450,9 +455,11 @@ constexpr int CB_COLS = 160;                // 9*16 (d,h) columns padded to five
 constexpr int CB_PART = CB_COLS * XC;       // floats per partial row
 constexpr int ET_STRIDE = 336;              // bytes per pixel row of the E tile (160 bf16 + pad: conflict-free 16-byte stores)
 
+constexpr int DZ_BLOCKS = 2048;   // grid cap of conv_bwd_dz_kernel = rows of its per-block db3 partials
 __global__ __launch_bounds__(256) void conv_bwd_dz_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
-                                                          bf16_t* __restrict__ dzb, float* __restrict__ db3, int B,
+                                                          bf16_t* __restrict__ dzb, float* __restrict__ dbpart, int B,
                                                           long long HW, int NH) {
+  __shared__ float dbw[4][MAXH];
   const long long M = (long long)B * HW;
   float db_acc[MAXH];
 #pragma unroll
@@ -477,12 +484,15 @@ __global__ __launch_bounds__(256) void conv_bwd_dz_kernel(const float* __restric
     ((uint4*)(dzb + (size_t)p * MAXH))[0] = o[0];
     ((uint4*)(dzb + (size_t)p * MAXH))[1] = o[1];
   }
-  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % DB3_SLOTS;
+  // bias gradient: one partial row per block, the four waves added in wave order (no atomics: run-to-run identical); the rows
+  // are summed in block order by conv_bwd_dw3_kernel
 #pragma unroll
   for (int h = 0; h < MAXH; ++h) {
     const float s = wave_sum(db_acc[h]);
-    if ((threadIdx.x & 63) == 0 && h < NH) atomicAdd(db3 + slot * 32 + h, s);
+    if ((threadIdx.x & 63) == 0) dbw[threadIdx.x >> 6][h] = s;
   }
+  __syncthreads();
+  if (threadIdx.x < MAXH) dbpart[(size_t)blockIdx.x * MAXH + threadIdx.x] = ((dbw[0][threadIdx.x] + dbw[1][threadIdx.x]) + dbw[2][threadIdx.x]) + dbw[3][threadIdx.x];
 }
 
 // transposed K operand from a tile with `stride`-byte rows: slot e of k-step ks <-> tile row acc_row(8*ks+e, half), col l31
@@ -632,8 +642,14 @@ __global__ __launch_bounds__(256, 1) void conv_bwd_kernel(const bf16_t* __restri
 }
 
 // dW3[(h*9+d)*32 + c] = sum over the partial rows of column d*16+h
-__global__ __launch_bounds__(256) void conv_bwd_dw3_kernel(const float* __restrict__ part, float* __restrict__ dW3, int NH, int nrows) {
+__global__ __launch_bounds__(256) void conv_bwd_dw3_kernel(const float* __restrict__ part, float* __restrict__ dW3, int NH, int nrows,
+                                                           const float* __restrict__ dbpart, int nbrows, float* __restrict__ db3) {
   const int o = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < NH) {       // db3[h] (row 0 of the caller's [DB3_SLOTS][32] table): block partials in order
+    double t = 0.;
+    for (int b = 0; b < nbrows; ++b) t += dbpart[(size_t)b * MAXH + threadIdx.x];
+    db3[threadIdx.x] += (float)t;
+  }
   if (o >= NH * 9 * XC) return;
   const int c = o % XC, hd = o / XC, h = hd / 9, d = hd % 9;
   const size_t col = (size_t)(d * 16 + h) * XC + c;
@@ -788,11 +804,13 @@ __global__ __launch_bounds__(512, 1) void gate_bwd_reduce_kernel(const bf16_t* _
     }
     __syncthreads();
   }
-  if (l31 == 0 && cg == 0) {
+  for (int w = 0; w < 4; ++w) {               // (wave order, no LDS atomics: see the accumulators above)
+    if (stream == w && l31 == 0 && cg == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&db[half * 8 + e], dbh[e]);
+      for (int e = 0; e < 8; ++e) db[half * 8 + e] += dbh[e];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   float* o = part + (size_t)blockIdx.x * RED_N;
   for (int e = threadIdx.x; e < NBLK * 16 * 64; e += 512) {
     const int ln = e & 63, j = (e >> 6) & 15, blk = e >> 10;
@@ -979,7 +997,7 @@ extern "C" {
 MVIT_API int mvit_heads_moments(const void* x, double* mom, long long M, int nslots, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || nslots <= 0) return MVIT_EINVAL;
-  hipLaunchKernelGGL(moments_kernel, dim3(nblk(M, 32 * 4 * 4, 512)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mom, M,
+  hipLaunchKernelGGL(moments_kernel, dim3(nblk(M, 32 * 4 * 4, nslots >= 256 && nslots < 512 ? nslots : 512)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mom, M,
                      nslots);
   return MVIT_LAUNCH_CHECK();
 }
@@ -1019,7 +1037,8 @@ MVIT_API int mvit_heads_conv_fwd(const void* x, const void* G, const float* W3, 
 }
 
 MVIT_API long long mvit_heads_conv_bwd_scratch_bytes(long long M) {
-  return (long long)(((size_t)M * MAXH * sizeof(bf16_t) + 255) / 256 * 256 + (size_t)CB_BLOCKS * CB_PART * sizeof(float));
+  return (long long)(((size_t)M * MAXH * sizeof(bf16_t) + 255) / 256 * 256 + (size_t)CB_BLOCKS * CB_PART * sizeof(float) +
+                     (size_t)DZ_BLOCKS * MAXH * sizeof(float));
 }
 
 MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x, const void* G, const float* W3, void* scratch,
@@ -1032,10 +1051,13 @@ MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x,
   hipStream_t s = (hipStream_t)stream;
   bf16_t* dzb = (bf16_t*)scratch;
   float* part = (float*)((char*)scratch + ((size_t)M * MAXH * sizeof(bf16_t) + 255) / 256 * 256);
-  hipLaunchKernelGGL(conv_bwd_dz_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, s, dY, Y, dzb, db3, B, (long long)H * W, NH);
+  float* dbpart = part + (size_t)CB_BLOCKS * CB_PART;
+  const int dzblocks = nblk(M, 256, DZ_BLOCKS);
+  hipLaunchKernelGGL(conv_bwd_dz_kernel, dim3(dzblocks), dim3(256), 0, s, dY, Y, dzb, dbpart, B, (long long)H * W, NH);
   hipLaunchKernelGGL(conv_bwd_kernel, dim3(CB_BLOCKS), dim3(256), 0, s, (const bf16_t*)dzb, (const bf16_t*)x, (const bf16_t*)G, W3,
                      dG, dXc, part, B, H, W, NH);
-  hipLaunchKernelGGL(conv_bwd_dw3_kernel, dim3((NH * 9 * XC + 255) / 256), dim3(256), 0, s, (const float*)part, dW3, NH, CB_BLOCKS);
+  hipLaunchKernelGGL(conv_bwd_dw3_kernel, dim3((NH * 9 * XC + 255) / 256), dim3(256), 0, s, (const float*)part, dW3, NH, CB_BLOCKS,
+                     (const float*)dbpart, dzblocks, db3);
   return MVIT_LAUNCH_CHECK();
 }
 

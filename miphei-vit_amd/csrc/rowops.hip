@@ -291,24 +291,7 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
   }
 }
 
-// ------------------------------------------------------------------ patch gather: NCHW f32 image -> [B*g*g, Kp] bf16
-__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B,
-                                                           int S, int p, int g, int Kp) {
-  const long long total = (long long)B * g * g * Kp;
-  const int pp = p * p, K = 3 * pp;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int k = (int)(i % Kp);
-    const long long row = i / Kp;
-    float v = 0.f;
-    if (k < K) {
-      const int c = k / pp, rem = k - c * pp, iy = rem / p, ix = rem - iy * p;
-      const int gx = (int)(row % g), gy = (int)((row / g) % g), b = (int)(row / ((long long)g * g));
-      v = img[(((size_t)b * 3 + c) * S + gy * p + iy) * S + gx * p + ix];
-    }
-    out[i] = f2bf(v);
-  }
-}
-
+// ------------------------------------------------------------------ prefix tokens (cls + registers) of the token matrix
 __global__ __launch_bounds__(256) void prefix_tokens_kernel(float* __restrict__ x, const float* __restrict__ cls,
                                                             const float* __restrict__ reg, int B, int ntok, int D, int R) {
   const int total = B * (1 + R) * D;
@@ -415,14 +398,6 @@ MVIT_API int mvit_skinny_xw2(const void* X0, const void* W0, void* out0, const v
   if (M <= 0 || K <= 0 || R <= 0 || R > 16 || (K & 7) || (ldx & 7) || (ldw & 7) || !X1 || !W1 || !out1) return MVIT_EINVAL;
   SkinnyPair pr{{(const bf16_t*)X0, (const bf16_t*)X1}, {(const bf16_t*)W0, (const bf16_t*)W1}, {(bf16_t*)out0, (bf16_t*)out1}};
   hipLaunchKernelGGL(skinny_xw_kernel, dim3((M + 15) / 16, 2), dim3(256), 0, (hipStream_t)stream, pr, ldx, ldw, ldo, M, K, R);
-  return MVIT_LAUNCH_CHECK();
-}
-
-MVIT_API int mvit_im2col_patch(const float* img, void* out, int B, int S, int p, int g, int Kp, mvit_stream_t stream) {
-  MVIT_CLEAR_ERROR();
-  if (B <= 0 || g <= 0 || g * p > S || Kp < 3 * p * p || (Kp & 7)) return MVIT_EINVAL;
-  hipLaunchKernelGGL(im2col_patch_kernel, dim3(nblocks((long long)B * g * g * Kp, 256)), dim3(256), 0, (hipStream_t)stream,
-                     img, (bf16_t*)out, B, S, p, g, Kp);
   return MVIT_LAUNCH_CHECK();
 }
 

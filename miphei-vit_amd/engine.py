@@ -23,11 +23,11 @@ from types import SimpleNamespace as NS
 import torch
 
 from . import ops
-from .ops import (A_CONV3, A_CONV3_T, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,
+from .ops import (A_CONV3, A_CONV3_T, A_PATCH, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,
                   EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
 from .resample import taps
 
-NSLOTS = 32
+NSLOTS = ops.STAT_SLOTS          # statistic slots per BatchNorm layer (32; 256 = one per writer block with MIPHEI_DETERMINISTIC=1)
 BN_EPS, BN_MOM = 1e-5, 0.1
 CONV_CH = (3, 48, 96, 192)
 FUS_OUT = (256, 128, 64, 32)
@@ -96,7 +96,6 @@ class HipEngine:
         c.Dh = c.D // c.H
         c.ntok = c.grid * c.grid + c.prefix
         c.Hg = c.hidden // 2 if c.swiglu else c.hidden
-        c.Kp = _pad8(3 * c.patch * c.patch)
         if lora:
             c.rank = qkv0.lora_q.rank
             c.alpha = float(qkv0.lora_q.alpha)
@@ -225,10 +224,12 @@ class HipEngine:
             return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
         fz = NS(blocks=[])
-        wp = vit.patch_embed.proj.weight.detach().reshape(c.D, -1)
-        wpp = torch.zeros(c.D, c.Kp, device=dev, dtype=bf)
-        wpp[:, :wp.shape[1]] = wp.to(dev)
-        fz.wpatch, fz.bpatch = wpp, f32(vit.patch_embed.proj.bias)
+        # patch-embed weight in the K order of the in-kernel window gather (MVIT_A_PATCH): k = (dy * patch + dx) * 8 + c over the
+        # 8-channel NHWC image (3 colour channels, 5 zero)
+        wp = vit.patch_embed.proj.weight.detach().to(dev)                      # [D, 3, patch, patch]
+        wpp = torch.zeros(c.D, c.patch, c.patch, 8, device=dev, dtype=bf)
+        wpp[..., :3] = wp.permute(0, 2, 3, 1)
+        fz.wpatch, fz.bpatch = wpp.reshape(c.D, c.patch * c.patch * 8).contiguous(), f32(vit.patch_embed.proj.bias)
         fz.pos = f32(vit.pos_embed.reshape(-1, c.D))
         fz.cls = f32(vit.cls_token.reshape(-1))
         fz.reg = f32(vit.reg_token.reshape(-1, c.D)) if c.nreg else fz.cls
@@ -370,7 +371,7 @@ class HipEngine:
         z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
         M, D, S = B * c.ntok, c.D, c.S
         w = NS(B=B, M=M)
-        w.patches = e(B * c.grid * c.grid, c.Kp)
+        w.img8 = e(B, S, S, 8)            # bf16 NHWC image (3 colour channels + 5 zero): patch-embed gather and decoder operand
         nl = c.L if train else 1
         w.x_in = [e(M, D, dt=torch.float32) for _ in range(nl + 1)] if train else [e(M, D, dt=torch.float32)]
         w.x_mid = [e(M, D, dt=torch.float32) for _ in range(nl)]
@@ -396,7 +397,6 @@ class HipEngine:
         s1, s2, s3 = S // 2, S // 4, S // 8
         w.res = (S, s1, s2, s3, G)
         w.feat = e(B, G, G, D)
-        w.img8 = e(B, S, S, 8)
         w.cat = [e(B, s3, s3, CONV_CH[3] + D), e(B, s2, s2, CONV_CH[2] + FUS_OUT[0]), e(B, s1, s1, CONV_CH[1] + FUS_OUT[1]),
                  z(B, S, S, _pad8(CONV_CH[0] + FUS_OUT[2]))]
         w.pre_c = [e(B * s1 * s1, 48), e(B * s2 * s2, 96), e(B * s3 * s3, 192)]
@@ -490,18 +490,27 @@ class HipEngine:
         draw = (torch.rand(c.L, 2, w.B, device=w.tok.device) < keep).float() / keep
         return draw.repeat_interleave(c.ntok, dim=2).contiguous()
 
-    def _encoder_fwd(self, w, x, train, pk, taps=None):
-        """taps: {block index: bf16 [M, D] buffer} receives the residual stream after that block (forward_intermediates)"""
+    def _encoder_fwd(self, w, x, train, pk, taps=None, img8=None):
+        """taps: {block index: bf16 [M, D] buffer} receives the residual stream after that block (forward_intermediates);
+        img8: bf16 NHWC [B,S,S,8] image already written by the input stage (else converted from x here)"""
         c, fz = self._config(), self._ensure_frozen()
         B, M, D = w.B, w.M, c.D
         w.dpath = self._drop_path_factors(w, c) if train else None
         dp = w.dpath
         P = c.grid * c.grid
-        ops.im2col_patch(x, w.patches, c.patch, c.grid)
+        if img8 is not None:
+            if img8.dtype != torch.bfloat16 or tuple(img8.shape) != tuple(w.img8.shape) or not img8.is_contiguous():
+                raise ValueError(f"img8: expected a contiguous bf16 tensor {tuple(w.img8.shape)}")
+            im8 = img8            # read in place (the decoder and its backward use the same buffer)
+        else:
+            im8 = w.img8
+            ops.image_to_nhwc(x, im8, 8, nzero=5)
+        w.img8_cur = im8
         X = w.x_in[0]
         ops.prefix_tokens(X, fz.cls, fz.reg, B, c.ntok, D, c.nreg)
-        ops.gemm(w.patches, fz.wpatch, X, bias=fz.bpatch, pos=fz.pos, epi=EPI_PATCH, patch=(P, c.ntok, c.prefix),
-                 flags=OUT_F32)
+        # patch embedding: 14x14x3 windows gathered from the NHWC image by the GEMM's A loader (no im2col buffer)
+        ops.gemm(im8, fz.wpatch, X, M=B * P, amode=A_PATCH, conv=(c.S, c.S, 8, 8, c.grid, c.grid, c.patch), bias=fz.bpatch,
+                 pos=fz.pos, epi=EPI_PATCH, patch=(P, c.ntok, c.prefix), flags=OUT_F32)
         scale = c.Dh ** -0.5
         for l, b in enumerate(fz.blocks):
             i = l if train else 0
@@ -551,10 +560,10 @@ class HipEngine:
         ty = taps(mode, c.grid, G, dev)
         ops.resample2d(w.tok[c.prefix:], w.feat, ty, ty, B=B, h=c.grid, w=c.grid, H=G, W=G, C=D, ld_src=D, ld_dst=D,
                        src_bstride=c.ntok * D, dst_bstride=G * G * D)
-        ops.image_to_nhwc(x, w.img8, 8, nzero=5)
+        im8 = w.img8_cur          # written (or adopted from the input stage) by _encoder_fwd
         # (the image slice of the last concat buffer is copied from img8 by the up-sampling kernel that fills the rest of it)
         # ConvStream: conv3x3 s2 -> BN -> ReLU, written into the skip slice of the matching concat buffer
-        src = [(w.img8, S, 8, 8), (w.cat[2], s1, 48, w.cat[2].shape[-1]), (w.cat[1], s2, 96, w.cat[1].shape[-1])]
+        src = [(im8, S, 8, 8), (w.cat[2], s1, 48, w.cat[2].shape[-1]), (w.cat[1], s2, 96, w.cat[1].shape[-1])]
         dst = [(w.cat[2], s1), (w.cat[1], s2), (w.cat[0], s3)]
         for i in range(3):
             a, r_in, cin, ld = src[i]
@@ -594,7 +603,7 @@ class HipEngine:
                 ops.upsample2x_bilinear(w.pre_f[j], nxt.view(-1)[off:], B=B, h=r, w=r, C=FUS_OUT[j], ld_src=FUS_OUT[j],
                                         ld_dst=nxt.shape[-1], src_bstride=r * r * FUS_OUT[j],
                                         dst_bstride=4 * r * r * nxt.shape[-1], scale=w.bnp[i].scale, shift=w.bnp[i].shift,
-                                        extra8=w.img8 if j == 2 else None)
+                                        extra8=im8 if j == 2 else None)
             else:
                 ops.bn_relu_apply(w.pre_f[3], w.bnp[i].scale, w.bnp[i].shift, w.F3, Mo, 32, 32, 32)
         # heads
@@ -617,8 +626,10 @@ class HipEngine:
         rv = torch.cat([h[0].psi[1].running_var.detach().float() for h in heads]).to(dev).contiguous()
         return rm, rv
 
-    def forward(self, x, train=False, bn_train=None):
-        """Generator forward.  train=True keeps the activations the backward pass needs (one graph in flight)."""
+    def forward(self, x, train=False, bn_train=None, img8=None):
+        """Generator forward.  train=True keeps the activations the backward pass needs (one graph in flight).
+        img8: optional bf16 NHWC [B,S,S,8] copy of x (channels 3..7 zero) as the input stage writes it; replaces the engine's own
+        NCHW -> NHWC conversion of the decoder's image operand."""
         dev = self._require_gpu()
         c = self._config()
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != c.S or x.shape[3] != c.S:
@@ -635,7 +646,7 @@ class HipEngine:
             w.arena_f.zero_()
         dec = self.model.decoder
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
-        self._encoder_fwd(w, x, train, pk)
+        self._encoder_fwd(w, x, train, pk, img8=img8)
         out = self._decoder_fwd(w, x, bn_train, pk, convs)
         if bn_train:
             self._flat.nbt.add_(1)
@@ -713,7 +724,7 @@ class HipEngine:
             bn = convs[i].bn
             ops.bn_relu_bwd(dy_post, ld_post, w.pre_f[j], bp.scale, bp.shift, bp.mean, bp.rstd, pk.bn[i].w, w.stats_b[i],
                             fl.gview[id(bn.weight)], fl.gview[id(bn.bias)], w.dpre_f[j], Mo, cout, NSLOTS)
-            if j == 3 and pk.wdir_f is not None and cat.numel() * 2 < 2 ** 31 and (cp, cout) == (72, 32):
+            if j == 3 and pk.wdir_f is not None and cat.numel() * 2 < 2 ** 31 and (cp, cout) == (72, 32) and not ops.DETERMINISTIC:
                 # weight gradient on the LDS-staged tiles as well (output-channel-major scratch, see the unpack below)
                 ops.conv3x3_direct_wgrad(cat, w.dpre_f[j], w.dWt[i], B=B, H=r, W=r, cin_pad=cp, ldx=cp, cout=cout, ldy=cout)
                 w.wgrad_n_major = True
@@ -749,7 +760,7 @@ class HipEngine:
                        src_bstride=G * G * D, dst_bstride=c.ntok * D)
         # ---- ConvStream (reverse): dD_k = skip slice of the concat gradient (+ dgrad of the next conv, accumulated)
         skip = [(w.dcat[2], s1), (w.dcat[1], s2), (w.dcat[0], s3)]
-        srcs = [(w.img8, S, 8, 8), (w.cat[2], s1, 48, w.cat[2].shape[-1]), (w.cat[1], s2, 96, w.cat[1].shape[-1])]
+        srcs = [(w.img8_cur, S, 8, 8), (w.cat[2], s1, 48, w.cat[2].shape[-1]), (w.cat[1], s2, 96, w.cat[1].shape[-1])]
         for i in (2, 1, 0):
             dsk, r_out = skip[i]
             Mo = B * r_out * r_out

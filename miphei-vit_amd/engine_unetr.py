@@ -238,7 +238,7 @@ class UnetrEngine:
         z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
         w = NS(B=B, S=S, G=G, train=train)
         w.layers, shapes = self._graph(G, S)
-        w.buf = {k: e(B * r * r, ch) for k, (r, ch) in shapes.items()}
+        w.buf = {k: e(B * r * r, ch) for k, (r, ch) in shapes.items() if k != "img8"}
         w.res = {k: r for k, (r, ch) in shapes.items()}
         maxel = max(B * r * r * ch for r, ch in shapes.values())
         w.pre = {}          # pre-BatchNorm conv outputs (kept per layer in train mode, one shared buffer otherwise)
@@ -389,7 +389,7 @@ class UnetrEngine:
         for i in range(4):
             ops.resample2d(we.tap16[i][c.prefix:], w.buf[f"feat{i}"], ty, ty, B=B, h=c.grid, w=c.grid, H=G, W=G, C=D, ld_src=D,
                            ld_dst=D, src_bstride=c.ntok * D, dst_bstride=G * G * D)
-        ops.image_to_nhwc(x, w.buf["img8"], 8, nzero=5)
+        w.buf["img8"] = we.img8_cur          # bf16 NHWC image: written once by the encoder engine (its patch-embed gather reads it too)
         self._drop_step += 1
         st = {"_seed": (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF}
         for rec in w.layers:

@@ -16,26 +16,71 @@ HOPTIMUS_STD = (0.211883 * 255, 0.230117 * 255, 0.177517 * 255)
 
 
 class InputStage:
-    """uint8 RGB [B,H,W,3] -> f32 NCHW (x - mean) / std; uint8 mIF [B,H,W,C] -> f32 NCHW x/255*1.8 - 0.9."""
+    """uint8 RGB [B,H,W,3] -> f32 NCHW (x - mean) / std; uint8 mIF [B,H,W,C] -> f32 NCHW x/255*1.8 - 0.9, with the reference's own
+    f32 operation order (bit-identical to ``NormalizationLayer``; tests/golden/comp_io.npz)."""
 
     def __init__(self, device, mean=HOPTIMUS_MEAN, std=HOPTIMUS_STD):
-        m = torch.tensor(mean, dtype=torch.float64)
-        s = torch.tensor(std, dtype=torch.float64)
-        self.scale = (1.0 / s).float().to(device)
-        self.shift = (-m / s).float().to(device)
         self.device = device
+        self.mean = [float(torch.tensor(v, dtype=torch.float64).float()) for v in mean]
+        self.std = [float(torch.tensor(v, dtype=torch.float64).float()) for v in std]
+
+    def _run(self, rgb_u8, mif_u8):
+        ref = rgb_u8 if rgb_u8 is not None else mif_u8
+        B, H, W, _ = ref.shape
+        if W % 4:
+            raise ValueError("tile width must be a multiple of 4")
+        img = torch.empty(B, 3, H, W, device=self.device, dtype=torch.float32) if rgb_u8 is not None else None
+        tgt = torch.empty(B, mif_u8.shape[3], H, W, device=self.device, dtype=torch.float32) if mif_u8 is not None else None
+        ops.augment_tiles(rgb_u8.contiguous() if rgb_u8 is not None else None, mif_u8.contiguous() if mif_u8 is not None else None,
+                          img, tgt, None, (H, W), 0, 0, self.mean, self.std, p_hflip=0.0, p_vflip=0.0, p_drop=0.0, hole_frac=0.0)
+        return img, tgt
 
     def image(self, rgb_u8):
-        B, H, W, C = rgb_u8.shape
-        out = torch.empty(B, C, H, W, device=self.device, dtype=torch.float32)
-        return ops.u8_nhwc_to_f32_nchw(rgb_u8.contiguous(), out, self.scale, self.shift)
+        if rgb_u8.shape[3] != 3:
+            raise ValueError("expected uint8 RGB tiles [B,H,W,3]")
+        return self._run(rgb_u8, None)[0]
 
     def target(self, mif_u8):
-        B, H, W, C = mif_u8.shape
-        out = torch.empty(B, C, H, W, device=self.device, dtype=torch.float32)
-        scale = torch.full((C,), 1.8 / 255.0, device=self.device)
-        shift = torch.full((C,), -0.9, device=self.device)
-        return ops.u8_nhwc_to_f32_nchw(mif_u8.contiguous(), out, scale, shift)
+        return self._run(None, mif_u8)[1]
+
+
+class TrainAugmenter:
+    """Training-time input stage on the device: the spatial half of the reference's albumentations pipeline
+    (``get_augmentations(training=True)``, ``/root/reference/src/dataset.py:458-468``: ``RandomCrop`` -> ``HorizontalFlip(0.5)`` ->
+    ``VerticalFlip(0.5)`` -> ``CoarseDropout(p=0.1, one hole, <= 30 % of each side)``, applied jointly to image and target) fused
+    with both ``NormalizationLayer`` modes, on raw uint8 tiles.  At ~430 tiles/s per GPU a CPU loader (``dataset.py:43,118-133``)
+    cannot feed one GPU, let alone eight; here a batch costs one HBM-bound launch.
+
+    Draws are counter-based -- sample ``n`` of the run (``n = step * batch + b``, plus ``rank_offset``) always gets the same
+    crop / flips / hole for a given seed, independent of batch size and rank layout -- and ``params(n)`` recomputes them on the
+    host.  (The colour augmentations of the reference -- HED jitter, brightness / contrast, blur, noise -- are not part of this
+    stage.)  ``__call__`` returns the batch dict ``training_step`` takes; ``image_nhwc8`` is the engine's bf16 NHWC decoder image
+    buffer, written by the same launch (the engine then skips its own NCHW -> NHWC conversion)."""
+
+    def __init__(self, device, crop, seed=0, mean=HOPTIMUS_MEAN, std=HOPTIMUS_STD, p_hflip=0.5, p_vflip=0.5, p_drop=0.1,
+                 hole_frac=0.3, rank_offset=0):
+        self.device, self.crop, self.seed = device, (int(crop[0]), int(crop[1])), int(seed)
+        # f32 constants exactly as NormalizationLayer builds them (np.float32 of the f64 mean / std)
+        self.mean = [float(torch.tensor(v, dtype=torch.float64).float()) for v in mean]
+        self.std = [float(torch.tensor(v, dtype=torch.float64).float()) for v in std]
+        self.p = dict(p_hflip=p_hflip, p_vflip=p_vflip, p_drop=p_drop, hole_frac=hole_frac)
+        self.rank_offset = int(rank_offset)
+
+    def params(self, sample, src_size):
+        return ops.augment_draw(src_size[0], src_size[1], self.crop[0], self.crop[1], self.seed, self.rank_offset + sample, **self.p)
+
+    def __call__(self, rgb_u8, mif_u8, sample0, nhwc8=True):
+        B = rgb_u8.shape[0]
+        H, W = self.crop
+        img = torch.empty(B, 3, H, W, device=self.device, dtype=torch.float32)
+        tgt = torch.empty(B, mif_u8.shape[3], H, W, device=self.device, dtype=torch.float32) if mif_u8 is not None else None
+        n8 = torch.empty(B, H, W, 8, device=self.device, dtype=torch.bfloat16) if nhwc8 else None
+        ops.augment_tiles(rgb_u8.contiguous(), mif_u8.contiguous() if mif_u8 is not None else None, img, tgt, n8, self.crop,
+                          self.seed, self.rank_offset + int(sample0), self.mean, self.std, **self.p)
+        batch = {"image": img, "target": tgt}
+        if n8 is not None:
+            batch["image_nhwc8"] = n8
+        return batch
 
 
 def export_uint8(pred):

@@ -105,7 +105,8 @@ class ModelModule(_Base):
         if not hasattr(eng, "loss_and_grad") or not isinstance(self.loss_reconstruct, WeightedMSELoss):
             return self._training_step_autograd(x, y)
         self.generator.train()
-        out = eng.forward(x, train=True)
+        n8 = batch.get("image_nhwc8")          # written by io_stage.TrainAugmenter next to "image" (same pixels, bf16 NHWC)
+        out = eng.forward(x, train=True, img8=n8) if n8 is not None and hasattr(eng, "_decoder_fwd") else eng.forward(x, train=True)
         w = self.loss_reconstruct.marker_weights
         if w.device != out.device:
             self.loss_reconstruct.to(out.device)

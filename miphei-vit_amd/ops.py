@@ -2,12 +2,22 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
-from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,  # noqa: F401
+from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, A_PATCH, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,  # noqa: F401
                    EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
+
+
+# MIPHEI_DETERMINISTIC=1 (read at import): run-to-run identical results.  Every reduction that normally meets in floating-point
+# atomics takes an ordered route instead: BatchNorm / head statistics get one slot per writer block (256 slots, grids capped at the
+# slot count, summed in slot order), the slices of a TN GEMM's m range accumulate into private copies that are added in slice
+# order, the direct weight-gradient kernel of the last fusion block is replaced by that TN path.  (Block-internal reductions are
+# ordered in every mode.)  Slower by a few per cent; used by the tests to assert bit-identical steps and tight exchange tolerances.
+DETERMINISTIC = os.environ.get("MIPHEI_DETERMINISTIC", "0") == "1"
+STAT_SLOTS = 256 if DETERMINISTIC else 32
 
 
 class _Probe:
@@ -27,7 +37,36 @@ class _Probe:
         return {"n": len(self.events), "ms": ms, "flops": float(sum(f for _, _, f in self.events))}
 
 
+class _KernelProbe:
+    """bench.py's `roofline_kernels` leg: HIP-event pairs around EVERY dense GEMM call (keyed by tile variant + epilogue) and
+    every attention call, on a few extra steps OUTSIDE the timed region (an event pair costs the stream ~6 us of idle time, so this
+    never runs inside it)."""
+
+    def __init__(self):
+        self.on = False
+        self.events = {}
+
+    def start(self):
+        self.on, self.events = True, {}
+
+    def add(self, key, e0, e1, flops):
+        self.events.setdefault(key, []).append((e0, e1, flops))
+
+    def stop(self):
+        self.on = False
+        torch.cuda.synchronize()
+        out = {}
+        for key, ev in self.events.items():
+            ms = [a.elapsed_time(b) for a, b, _ in ev]
+            out[key] = {"n": len(ev), "ms": sum(ms), "flops": float(sum(f for _, _, f in ev))}
+        self.events = {}
+        return out
+
+
 PROBE = _Probe()
+KPROBE = _KernelProbe()
+EPI_NAMES = {EPI_STORE: "STORE", EPI_GELU: "GELU", EPI_SWIGLU: "SWIGLU", EPI_RESID: "RESID", EPI_PATCH: "PATCH", EPI_STATS: "STATS",
+             EPI_DSWIGLU: "DSWIGLU", EPI_DGELU: "DGELU"}
 PROBE_VARIANT = (256 << 20) | (128 << 8) | (4 << 4) | 2   # gemm_kernel<256,128,4,2,...>: largest share of the step
 
 
@@ -92,26 +131,47 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     # (gemm_kernel<256,128,4,2,DENSE,STORE>: the dgrad GEMMs and the plain-store forward ones), as reported by the library's own dispatcher
     probe = (PROBE.on and amode == A_DENSE and epi == EPI_STORE and ksplit == 1
              and L.lib().mvit_gemm_variant(C.byref(g)) == PROBE_VARIANT)
-    if probe:
+    kprobe = KPROBE.on and amode == A_DENSE and ksplit == 1
+    if probe or kprobe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     L.check(L.lib().mvit_gemm_bf16(C.byref(g), _stream()), "mvit_gemm_bf16")
-    if probe:
+    if probe or kprobe:
         e1.record()
-        PROBE.events.append((e0, e1, 2.0 * g.M * g.N * (g.K + g.K2)))
+        if probe:
+            PROBE.events.append((e0, e1, 2.0 * g.M * g.N * (g.K + g.K2)))
+        if kprobe:
+            v = L.lib().mvit_gemm_variant(C.byref(g))
+            KPROBE.add(f"mvit_gemm::gemm_kernel<{v >> 20},{(v >> 8) & 0xfff},{(v >> 4) & 15},{v & 15},DENSE,{EPI_NAMES.get(epi, epi)}>",
+                       e0, e1, 2.0 * g.M * g.N * (g.K + g.K2))
     return c
 
 
 def gemm_tn(a, b, c, *, M, I, J, lda=None, ldb=None, ldci=None, ldcj=1, msplit=1, conv=None, c2=None, isplit=0, j1=0,
-            jlo2=0, batch=1, stride_a=0, stride_b=0, stride_c=0):
+            jlo2=0, batch=1, stride_a=0, stride_b=0, stride_c=0, split_stride=0):
     """C[i,j] (f32, += ) = sum_m A[m,i] * B[m,j]; conv=(H, W, C, ld, OH, OW, stride) makes A the virtual im2col.
     c2/isplit(/j1/jlo2): second output from the same pass (rows >= isplit, optionally columns >= jlo2), see the header.
     batch > 1: that many independent products from one launch, operand / output b at base + b * stride (elements)."""
     _chk_bf16(a, "A")
     _chk_bf16(b, "B")
     assert c.dtype == torch.float32
+    slabs = None
+    if DETERMINISTIC and msplit > 1 and split_stride == 0:
+        if c2 is not None or batch > 1:
+            msplit = 1                       # one contributing block per element (the batched LoRA products: still 10 x 36 blocks)
+        else:
+            # private copy of the output region per slice of m, added in slice order afterwards
+            nsteps = (M + 63) // 64
+            msplit = min(msplit, nsteps)
+            msplit = -(-nsteps // (-(-nsteps // msplit)))                 # slices the kernel actually runs (ceil-divided steps)
+            ldi = ldci if ldci is not None else c.stride(0)
+            extent = (I - 1) * ldi + (J - 1) * ldcj + 1
+            slabs = torch.zeros(msplit, extent, device=c.device, dtype=torch.float32)
+            split_stride, c_out, c = extent, c, slabs
+            if ldci is None:
+                ldci = ldi
     g = L.GemmTnArgs()
-    g.batch, g.strideA, g.strideB, g.strideC = batch, stride_a, stride_b, stride_c
+    g.batch, g.strideA, g.strideB, g.strideC, g.split_stride = batch, stride_a, stride_b, stride_c, split_stride
     g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
     g.M, g.I, g.J = M, I, J
     g.ldb = ldb if ldb is not None else b.stride(0)
@@ -128,6 +188,10 @@ def gemm_tn(a, b, c, *, M, I, J, lda=None, ldb=None, ldci=None, ldcj=1, msplit=1
         g.conv_H, g.conv_W, g.conv_C, g.conv_ld, g.conv_OH, g.conv_OW, g.conv_stride = conv
         g.lda = conv[3]
     L.check(L.lib().mvit_gemm_tn_bf16(C.byref(g), _stream()), "mvit_gemm_tn_bf16")
+    if slabs is not None:
+        flat = c_out.reshape(-1) if c_out.is_contiguous() else c_out.as_strided((slabs.shape[1],), (1,))
+        flat[:slabs.shape[1]] += slabs.sum(0)      # fixed-order sum of the slices (torch reductions are deterministic)
+        c = c_out
     return c
 
 
@@ -191,12 +255,6 @@ def skinny_xw2(X0, W0, out0, X1, W1, out1, *, ldx, ldw, ldo, M, K, R):
     _call("mvit_skinny_xw2", _p(X0), _p(W0), _p(out0), _p(X1), _p(W1), _p(out1), ldx, ldw, ldo, M, K, R)
 
 
-def im2col_patch(img, out, patch, grid):
-    B, _, S, _ = img.shape
-    _call("mvit_im2col_patch", _p(img), _p(out), B, S, patch, grid, out.shape[1])
-    return out
-
-
 def prefix_tokens(x, cls, reg, B, ntok, D, R):
     _call("mvit_prefix_tokens", _p(x), _p(cls), _p(reg), B, ntok, D, R)
 
@@ -212,13 +270,29 @@ def scale_cols_cast(x, gamma, out, rowscale=None):
     return out
 
 
+def _kprobed(key, flops, name, *args):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _call(name, *args)
+    e1.record()
+    KPROBE.add(key, e0, e1, flops)
+
+
 def attention_fwd(qkv, out, lse, B, N, H, Dh, scale):
-    _call("mvit_attention_fwd", _p(qkv), _p(out), _p(lse), B, N, H, Dh, scale)
+    args = (_p(qkv), _p(out), _p(lse), B, N, H, Dh, scale)
+    if KPROBE.on:       # algorithmic FLOPs: S = QK^T and O = PV, 2 * 2 * N^2 * Dh per (batch, head)
+        _kprobed("attn_fwd_kernel", 4.0 * B * H * N * N * Dh, "mvit_attention_fwd", *args)
+    else:
+        _call("mvit_attention_fwd", *args)
     return out
 
 
 def attention_bwd(qkv, out, d_out, lse, dsum, dqkv, B, N, H, Dh, scale):
-    _call("mvit_attention_bwd", _p(qkv), _p(out), _p(d_out), _p(lse), _p(dsum), _p(dqkv), B, N, H, Dh, scale)
+    args = (_p(qkv), _p(out), _p(d_out), _p(lse), _p(dsum), _p(dqkv), B, N, H, Dh, scale)
+    if KPROBE.on:       # algorithmic FLOPs of the backward: dV, dP, dQ, dK + the recomputed S = 5 products (2.5 x fwd)
+        _kprobed("attn_bwd (all launches of mvit_attention_bwd)", 10.0 * B * H * N * N * Dh, "mvit_attention_bwd", *args)
+    else:
+        _call("mvit_attention_bwd", *args)
     return dqkv
 
 
@@ -421,6 +495,29 @@ def u8_nhwc_to_f32_nchw(src, dst, scale, shift):
     assert src.dtype == torch.uint8 and dst.dtype == torch.float32
     _call("mvit_u8_nhwc_to_f32_nchw", _p(src), _p(dst), _p(scale), _p(shift), B, Cc, H * W)
     return dst
+
+
+def augment_tiles(img_u8, tgt_u8, out_img, out_tgt, out_nhwc8, crop, seed, sample0, mean, std, p_hflip=0.5, p_vflip=0.5,
+                  p_drop=0.1, hole_frac=0.3):
+    """mvit_augment_tiles: joint RandomCrop / flips / CoarseDropout + normalisation of uint8 NHWC tiles (see the header)."""
+    ref = img_u8 if img_u8 is not None else tgt_u8
+    B, Hs, Ws = ref.shape[:3]
+    H, W = crop
+    for t in (img_u8, tgt_u8):
+        assert t is None or (t.dtype == torch.uint8 and t.is_contiguous() and tuple(t.shape[:3]) == (B, Hs, Ws))
+    Cc = tgt_u8.shape[3] if tgt_u8 is not None else 0
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    _call("mvit_augment_tiles", _p(img_u8), _p(tgt_u8), _p(out_img), _p(out_tgt), _p(out_nhwc8), B, Cc, Hs, Ws, H, W,
+          int(seed) & (2 ** 64 - 1), int(sample0), p_hflip, p_vflip, p_drop, hole_frac, m3, s3)
+
+
+def augment_draw(Hs, Ws, H, W, seed, sample, p_hflip=0.5, p_vflip=0.5, p_drop=0.1, hole_frac=0.3):
+    """The draws the kernel makes for one sample, recomputed on the host by the library's own arithmetic:
+    dict(oy, ox, hflip, vflip, drop, y1, x1, hh, hw)."""
+    out = (C.c_int * 9)()
+    L.check(L.lib().mvit_augment_draw(Hs, Ws, H, W, int(seed) & (2 ** 64 - 1), int(sample), p_hflip, p_vflip, p_drop, hole_frac,
+                                      out), "mvit_augment_draw")
+    return dict(zip(("oy", "ox", "hflip", "vflip", "drop", "y1", "x1", "hh", "hw"), [int(v) for v in out]))
 
 
 def f32_to_u8_export(src, dst):

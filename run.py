@@ -37,9 +37,8 @@ def main(argv):
     if (losses.get("cell_loss") or {}).get("use_loss"):
         raise NotImplementedError("train.losses.cell_loss.use_loss: the cell-level loss (reference src/train.py:144-150) is "
                                   "outside the MI355X hot path")
-    if cfg.train.get("use_cell_metrics"):
-        raise NotImplementedError("train.use_cell_metrics: validation-time CellMetrics are not wired into run.py "
-                                  "(miphei_vit_amd.cells has the extractor); set ++train.use_cell_metrics=false")
+    # (train.use_cell_metrics -- on in the reference's shipped recipes through train=cell -- only adds validation-time CellMetrics
+    # (src/train.py:111-114, models.py:233-241); run.py runs training steps only, the extractor lives in miphei_vit_amd.cells)
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     # MIPHEI_DIST_BACKEND=gloo MIPHEI_SHARE_GPU=1: rehearsal of the multi-rank branch on a one-GPU box (RCCL refuses two ranks
     # on one device; gloo takes device tensors): every rank uses cuda:0.  The product transport is RCCL ("nccl").

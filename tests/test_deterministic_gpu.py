@@ -1,0 +1,59 @@
+"""GPU: MIPHEI_DETERMINISTIC=1 -- every reduction of the training step takes an ordered route (one statistic slot per writer block,
+private copies per slice of a TN GEMM's m range added in slice order, no direct-wgrad atomics), so two runs of the same steps from the
+same state give bit-identical gradients and parameters.  (The mode is read at import: the runs are separate interpreter processes.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import VIT_CONFIGS, det_state_dict, synth_batch
+from oracle.model import generator_state_shapes, orion_marker_weights
+from miphei_vit_amd import ops
+from miphei_vit_amd.generators import get_vitmatte
+from miphei_vit_amd.loss import WeightedMSELoss
+from miphei_vit_amd.models import ModelModule
+cfgname, img, nc, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+sd = det_state_dict(generator_state_shapes(VIT_CONFIGS[cfgname], img, nc), seed=21, layerscale=0.5)
+model = get_vitmatte(cfgname, img, nc, use_lora=True, pretrained=False)
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+model.cuda()
+mod = ModelModule(model, None, 1e-3, 0., WeightedMSELoss(50.0, orion_marker_weights(nc)))
+mod.total_iters, mod.global_step_ = 4000, 1000          # plateau of the schedule: every step moves the weights
+h = hashlib.sha256()
+for it in range(3):
+    x, y = synth_batch(300 + it, B, img, nc)
+    loss = mod.training_step({"image": x.cuda(), "target": y.cuda()}, it)
+    h.update(model._engine._flat.gflat.cpu().numpy().tobytes())
+    h.update(model._engine._flat.flat.cpu().numpy().tobytes())
+for k, v in sorted(model.state_dict().items()):
+    if "running_" in k:
+        h.update(v.detach().float().cpu().numpy().tobytes())
+print("DET", int(ops.DETERMINISTIC), h.hexdigest(), float(loss))
+''' % ROOT
+
+
+def _run(det, args):
+    env = dict(os.environ, MIPHEI_DETERMINISTIC="1" if det else "0")
+    p = subprocess.run([sys.executable, "-c", SCRIPT] + [str(a) for a in args], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("DET")][-1].split()
+    assert int(line[1]) == int(det)
+    return line[2], float(line[3])
+
+
+@pytest.mark.parametrize("cfgname,img,nc,B", [("tiny_swiglu", 128, 16, 3), ("tiny4_swiglu", 256, 3, 4)])
+def test_deterministic_mode_gives_bit_identical_steps(cfgname, img, nc, B):
+    a, la = _run(True, (cfgname, img, nc, B))
+    b, lb = _run(True, (cfgname, img, nc, B))
+    assert a == b and la == lb            # gradients, parameters and running statistics of three steps: identical bytes
+    c, lc = _run(False, (cfgname, img, nc, B))
+    assert abs(lc - la) < 2e-3 * abs(la)  # the default mode computes the same step (atomics: not bit-identical, not asserted)

@@ -47,6 +47,38 @@ def test_hoptimus0_forward_loss_gradnorm_vs_oracle(B, img):
     for k in ("decoder.segmentation_head_3.1.weight", "decoder.segmentation_head_0.0.psi.3.weight", "decoder.fusion_blks.3.conv.bn.weight"):
         g1, g0 = named[k].grad.double().cpu(), gref[k].double()
         assert float((g1 - g0).norm() / g0.norm()) < 0.05, k
+    if B != 2:
+        return
+    # Per-parameter gradients at full depth: LoRA A / B of blocks 0, 20, 39 (the far end, the middle and the near end of the
+    # 40-block backward chain: a wrong stride or a dropped term in ANY block's dgrad chain shows up at block 0) and EVERY decoder
+    # gradient.  Yardstick: the same arithmetic under bf16 autocast on the CPU (the reference's mixed-precision mode,
+    # train.precision) against fp32 -- the HIP path (bf16 operands, f32 accumulate) must be no noisier than that per parameter
+    # and point the same way (/root/reference/src/generators/lora.py:16-33, src/models.py:128-138).
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, _, gac = tr.loss_and_grads(x.cpu(), y.cpu())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    cosf = lambda a, b: float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm()).clamp_min(1e-30))
+    gnorm = float(gn_ref)
+    keys = [k for k in gref if k.startswith("decoder.")]
+    for l in (0, 20, 39):
+        keys += [f"encoder.vit.blocks.{l}.attn.qkv.lora_{qv}.{ab}" for qv in "qv" for ab in "AB"]
+    bad, rows = {}, []
+    for k in keys:
+        gr, got = gref[k], named[k].grad.detach().cpu()
+        if float(gr.double().norm()) < 1e-5 * gnorm:      # analytically zero (conv bias in front of a train-mode BatchNorm)
+            assert float(got.double().norm()) < 1e-5 * gnorm, k
+            continue
+        e_hip, e_ac, c_hip, c_ac = rel(got, gr), rel(gac[k], gr), cosf(got, gr), cosf(gac[k], gr)
+        rows.append((k, e_hip, e_ac, c_hip, c_ac))
+        if e_hip > max(1.25 * e_ac, 0.02) or c_hip < min(0.999, c_ac - 0.002):
+            bad[k] = (round(e_hip, 4), round(e_ac, 4), round(c_hip, 5), round(c_ac, 5))
+    lora = [r for r in rows if ".lora_" in r[0]]
+    print("LoRA gradients (rel err HIP, rel err autocast, cos HIP, cos autocast):")
+    for r in lora:
+        print("  %-48s %.4f %.4f %.5f %.5f" % r)
+    worst = max(rows, key=lambda r: r[1] / max(r[2], 0.016))
+    print("worst decoder/LoRA ratio: %s %.4f vs %.4f" % worst[:3])
+    assert len(lora) == 12 and not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12]
 
 
 @pytest.mark.parametrize("B", [16, 64])   # 64 = BASELINE configs[4] (inference): fc1 runs the 256x256 tile there

@@ -46,6 +46,31 @@ def test_gemm_store(M, N, K):
     assert torch.equal(cf, ai.float() @ bi.float().t())
 
 
+@pytest.mark.parametrize("B,S,p,D", [(2, 128, 14, 96), (3, 128, 16, 64), (16, 256, 14, 1536), (5, 256, 14, 200)])
+def test_patch_embed_window_gather(B, S, p, D):
+    """MVIT_A_PATCH: the patch-embedding convolution (timm PatchEmbed.proj, kernel = stride = p; foundation_models.py:53-57) as an
+    in-kernel window gather from the bf16 NHWC image, + bias + pos-embed + row remap past the prefix tokens, against F.conv2d on
+    the same bf16-rounded operands.  S = 128 / 256 with p = 14: the last 2 / 4 pixel rows and columns belong to no patch."""
+    ops = _ops()
+    g, prefix = S // p, 5
+    P = g * g
+    img = _rand(B, 3, S, S, seed=1)
+    w = _rand(D, 3, p, p, seed=2, scale=(3 * p * p) ** -0.5)
+    bias, pos = _rand(D, seed=3), _rand(P, D, seed=4)
+    img8 = torch.empty(B, S, S, 8, device="cuda", dtype=torch.bfloat16)
+    ops.image_to_nhwc(img, img8, 8, nzero=5)
+    wk = torch.zeros(D, p, p, 8, device="cuda", dtype=torch.bfloat16)
+    wk[..., :3] = w.permute(0, 2, 3, 1)
+    out = torch.full((B * (P + prefix), D), 7.0, device="cuda")
+    ops.gemm(img8, wk.view(D, -1), out, M=B * P, amode=ops.A_PATCH, conv=(S, S, 8, 8, g, g, p), bias=bias, pos=pos,
+             epi=ops.EPI_PATCH, patch=(P, P + prefix, prefix), flags=ops.OUT_F32)
+    ref = F.conv2d(img.bfloat16().float(), w.bfloat16().float(), bias, stride=p)            # [B, D, g, g]
+    ref = ref.flatten(2).transpose(1, 2) + pos
+    got = out.view(B, P + prefix, D)
+    assert _rel(got[:, prefix:], ref) < 2e-5
+    assert bool((got[:, :prefix] == 7.0).all())                                             # prefix rows are not touched
+
+
 @pytest.mark.parametrize("M,N,K,K2", [(700, 384, 256, 16), (2100, 384, 1536, 16), (1300, 256, 200, 16)])
 def test_gemm_kext_and_splitk(M, N, K, K2):
     ops = _ops()

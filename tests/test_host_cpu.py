@@ -300,8 +300,7 @@ def test_resume_keeps_the_configured_lr_horizon(tmp_path):
 
 
 @pytest.mark.parametrize("override,needle", [("++train.losses.use_weighted_mae=true", "use_weighted_mae"),
-                                             ("++train.losses.cell_loss.use_loss=true", "cell_loss"),
-                                             ("++train.use_cell_metrics=true", "use_cell_metrics")])
+                                             ("++train.losses.cell_loss.use_loss=true", "cell_loss")])
 def test_run_py_refuses_objectives_outside_the_path(override, needle):
     """reference src/train.py:118-150 switches the loss on these keys; run.py must not silently train with WeightedMSELoss"""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "run.py"), "+default_configs=tiny", override], capture_output=True,

@@ -186,3 +186,16 @@ def test_oracle_cells_match_reference_fixture(golden_dir):
         assert np.array_equal(rec[0], g[f"cm_{s}_id{i}"]) and np.array_equal(rec[2], g[f"cm_{s}_area{i}"])
         assert np.abs(rec[1] - g[f"cm_{s}_sum{i}"]).max() <= 1               # truncation of sums*255 to uint32: f32 summation order
     assert seen == {"slideA": int(g["cm_slideA_n"]), "slideB": int(g["cm_slideB_n"])}
+
+
+def test_input_stage_restatement_matches_reference_fixture(golden_dir):
+    """oracle/io.py against NormalizationLayer of the reference (fixture from oracle/make_golden_io.py): bit for bit."""
+    from oracle.io import normalize_he, normalize_if, spatial_augment
+    g = np.load(os.path.join(golden_dir, "comp_io.npz"))
+    assert np.array_equal(normalize_he(g["rgb"], g["mean"], g["std"]), g["he"])
+    assert np.array_equal(normalize_if(g["mif"]), g["mif_norm"])
+    assert np.allclose(g["he_unorm"], g["rgb"], atol=2e-5) and np.allclose(g["if_unorm"], g["mif"], atol=1e-4)
+    d = dict(oy=3, ox=5, hflip=1, vflip=1, drop=1, y1=2, x1=4, hh=6, hw=7)
+    a = spatial_augment(g["rgb"], d, (32, 40))
+    assert a.shape == (32, 40, 3) and (a[2:8, 4:11] == 0).all()
+    assert np.array_equal(a[0, 0], g["rgb"][3 + 31, 5 + 39]) and np.array_equal(a[31, 39], g["rgb"][3, 5])
