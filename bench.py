@@ -254,6 +254,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     if sync is not None:
         sync.exposed_events = []
+        sync.bucket_events = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -274,8 +275,9 @@ def main(argv=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     probe = ops.PROBE.stop()
+    comm = (sync.exposed_ms(), sync.bucket_report()) if (sync is not None and a.mode == "train") else None   # timed steps only
     kernels = None
-    if a.probe and a.mode == "train" and rank == 0:
+    if a.probe and a.mode == "train":       # (every rank: the extra steps run the gradient exchange too)
         # per-kernel roofline leg, OUTSIDE the timed region: two extra steps with an event pair around every dense GEMM call
         # (per tile variant + epilogue) and every attention call, so the weakest kernels are on the line, not only the dominant one
         ops.KPROBE.start()
@@ -309,9 +311,9 @@ def main(argv=None):
     }
     if dist.is_initialized():
         res["rccl_ranks"] = dist.get_world_size()
-        if sync is not None and a.mode == "train":
-            ex = sync.exposed_ms()
-            res["exposed_comm_ms_per_step"] = None if ex is None else round(ex, 4)
+        if comm is not None:
+            res["exposed_comm_ms_per_step"] = None if comm[0] is None else round(comm[0], 4)
+            res["comm_buckets"] = comm[1]      # per bucket: bytes, slack behind the backward pass, stall in finish()
             res["config"]["lora_buckets"] = a.lora_buckets
     if a.mode == "infer":
         # p50 latency of one batch, measured after the throughput window with a sync per batch

@@ -142,13 +142,16 @@ MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out_
 /* ---------------------------------------------------------------- fused multi-head attention */
 /* out(bf16)[B,N,H*Dh] = softmax(q k^T * scale) v per head, reading the packed projection qkv(bf16)[B,N,3,H,Dh];
  * lse(f32)[B,H,N] (optional) = log-sum-exp of the scaled scores, kept for the backward pass.  Dh <= 64, Dh % 8 == 0.
+ * out_res(bf16)[B,N,H*Dh] (optional, training) = the bf16 rounding residual of out: the backward pass forms
+ * D = sum_d dO * (out + out_res), consistent with its dP to ~16 bits (with the bf16 out alone dQ loses 20-30 % where attention is
+ * near-uniform: the D error does not cancel in dS = P (dP - D) as it does in the unfused softmax backward).
  * Replaces F.scaled_dot_product_attention inside timm Attention (model built at
  * src/generators/foundation_models.py:53-57; q,v carry LoRA deltas from src/generators/lora.py:29-33). */
-MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int Dh, float scale,
+MVIT_API int mvit_attention_fwd(const void* qkv, void* out, void* out_res, float* lse, int B, int N, int H, int Dh, float scale,
                                 mvit_stream_t stream);
-/* dqkv(bf16)[B,N,3,H,Dh] from d_out(bf16)[B,N,H*Dh]; dsum(f32)[B,H,N] is caller-provided scratch. */
-MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum,
-                                void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream);
+/* dqkv(bf16)[B,N,3,H,Dh] from d_out(bf16)[B,N,H*Dh]; dsum(f32)[B,H,N] is caller-provided scratch; out_res may be NULL. */
+MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* out_res, const void* d_out, const float* lse,
+                                float* dsum, void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- decoder data movement (NHWC bf16) */
 /* dst[b,oy,ox,c] = sum_{ty,tx} ty_w[oy,ty]*tx_w[ox,tx] * f(src[b, ty_idx[oy,ty], tx_idx[ox,tx], c]),
@@ -278,6 +281,20 @@ MVIT_API int mvit_conv3x3_direct_wgrad(const void* X, const void* dY, float* dWn
 MVIT_API int mvit_pack_conv3x3_direct(const float* W, void* out, int Cout, int Cin, int n_out, int k_in, int k_pad, int rot,
                                       int mode, mvit_stream_t stream);
 
+/* Direct 3x3 convolution (stride 1, pad 1, NHWC bf16) for the WIDE decoder layers -- Fusion_Block convs 1728 -> 256 @ 32^2,
+ * 352 -> 128 @ 64^2, 176 -> 64 @ 128^2 (src/generators/mipheivit.py:76-93) and their input gradients -- with LDS-staged input
+ * tiles: a work item is (8 x 32-pixel tile, 64-channel output slice), a step one 32-channel chunk of the input; the chunk's halo
+ * tile and its nine [64 x 32] weight taps are DMA'd into a two-slot LDS ring and all nine taps read the tile from there.
+ *   mvit_conv3x3_chunked_pack: nn.Conv2d weight [Cout,Cin,3,3] f32 -> the kernel's operand; mode 0 forward (n = output channel,
+ *     k = input channel), mode 1 input gradient (n = input channel of the forward conv, k = its output channel, taps flipped);
+ *     mvit_conv3x3_chunked_pack_elems(N, K) = bf16 elements of the packed operand.
+ *   mvit_conv3x3_chunked: Y[b,y,x,:Cout] = conv(X[b,y,x,:Cin]); stats (nullable): [nslots][2][Cout] f64 sum / sum of squares of
+ *     the f32 results (BatchNorm2d batch statistics), one slot per block when nslots >= the CU count.  Cin, Cout % 8 == 0. */
+MVIT_API long long mvit_conv3x3_chunked_pack_elems(int N, int K);
+MVIT_API int mvit_conv3x3_chunked_pack(const float* W, void* out_bf16, int Cout, int Cin, int mode, mvit_stream_t stream);
+MVIT_API int mvit_conv3x3_chunked(const void* X, const void* Wp, void* Y, double* stats, int nslots, int B, int H, int W, int Cin,
+                                  int ldx, int Cout, int ldy, mvit_stream_t stream);
+
 /* ---------------------------------------------------------------- per-step operand packs of the trainable tensors */
 /* LoRA adapters (src/generators/lora.py:8-33) from the flat f32 parameter region `lora` = L x [Aq [D,r] | Bq [r,D] | Av | Bv]
  * to the bf16 operands of the kernels, R2 = 2r: AcatT [L,R2,D], Acat [L,D,R2] (may be NULL), B2 [L,3D,R2] (alpha*B on the q
@@ -302,6 +319,9 @@ MVIT_API int mvit_unpack_conv3x3_wgrad_multi(const mvit_conv_unpack_desc* descs,
 MVIT_API int mvit_wmse_fwd_bwd(const float* pred, const float* target, const float* w, double* loss_acc, float* dY, int B,
                                int C, long long HW, float lambda_factor, mvit_stream_t stream);
 MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t stream);
+/* the same sum with the per-block partials (scratch: 256 doubles) added in block order by one thread instead of f64 atomics:
+ * run-to-run identical (the host's MIPHEI_DETERMINISTIC mode; torch.nn.utils.clip_grad_norm_ of src/models.py:136) */
+MVIT_API int mvit_sqnorm_ordered(const float* x, double* out, double* scratch256, long long n, mvit_stream_t stream);
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step on flat f32 buffers (src/models.py:136-138,359-371);
  * sqnorm = device scalar holding sum g^2 (no host sync), bias_c{1,2} = 1-beta^t.
  * NaN guard (src/models.py:102-105, `isnan(fake)` -> save weights -> raise): when *sqnorm is NaN/Inf, or *nonfinite_flag is

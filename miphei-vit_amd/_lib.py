@@ -57,6 +57,9 @@ SIGNATURES = {
     "mvit_layernorm_lora_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp],
     "mvit_conv3x3_direct_supported": [ci, ci],
     "mvit_conv3x3_direct": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "mvit_conv3x3_chunked_pack_elems": [ci, ci],
+    "mvit_conv3x3_chunked_pack": [vp, vp, ci, ci, ci, vp],
+    "mvit_conv3x3_chunked": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_pack_conv3x3_direct": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_lora_pack": [vp, vp, vp, vp, vp, ci, ci, ci, cf, vp],
     "mvit_unpack_conv3x3_wgrad": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
@@ -67,8 +70,8 @@ SIGNATURES = {
     "mvit_prefix_tokens": [vp, vp, vp, ci, ci, ci, ci, vp],
     "mvit_cast_f32_bf16": [vp, vp, C.c_longlong, vp],
     "mvit_scale_cols_cast": [vp, vp, vp, ci, ci, vp, vp],
-    "mvit_attention_fwd": [vp, vp, vp, ci, ci, ci, ci, cf, vp],
-    "mvit_attention_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
+    "mvit_attention_fwd": [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
+    "mvit_attention_bwd": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "mvit_resample2d": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ll, ll, ci, vp],
     "mvit_pack_conv3x3_weights_multi": [C.POINTER(ConvPackDesc), ci, vp],
     "mvit_unpack_conv3x3_wgrad_multi": [C.POINTER(ConvUnpackDesc), ci, vp],
@@ -94,6 +97,7 @@ SIGNATURES = {
     "mvit_pix_metrics_update": [vp, vp, vp, vp, ll, ci, ci, ci, ci, cf, cf, vp],
     "mvit_wmse_fwd_bwd": [vp, vp, vp, vp, vp, ci, ci, ll, cf, vp],
     "mvit_sqnorm": [vp, vp, ll, vp],
+    "mvit_sqnorm_ordered": [vp, vp, vp, ll, vp],
     "mvit_u8_nhwc_to_f32_nchw": [vp, vp, vp, vp, ci, ci, ll, vp],
     "mvit_f32_to_u8_export": [vp, vp, ll, vp],
     "mvit_augment_tiles": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, C.c_ulonglong, C.c_ulonglong, cf, cf, cf, cf, vp, vp, vp],
@@ -121,7 +125,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = C.c_longlong if name.endswith("_bytes") else C.c_int
+            fn.restype = C.c_longlong if name.endswith(("_bytes", "_elems")) else C.c_int
         _lib = handle
     return _lib
 

@@ -102,6 +102,32 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   return r.v;
 }
 
+// Epilogue store of one row per lane pair: lanes l and l + 32 hold the 4-column groups 8g + 4*half of the same row.  Packed groups
+// (g, g + 1) are exchanged with v_permlane32_swap so that each lane owns 8 consecutive columns and issues one 16-byte store per
+// pair (half the store instructions of the 8-byte form; cdna_hip_programming.md T21).  Dh % 16 != 0 keeps the 8-byte form.
+__device__ __forceinline__ void store_row_groups(bf16_t* row, int Dh, int half, const uint2 (&w)[2][4], bool ok) {
+  if (Dh & 15) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * half;
+        if (ok && d < Dh) *(uint2*)(row + d) = w[dt][g];
+      }
+    return;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      uint2 a = w[dt][2 * pr], b = w[dt][2 * pr + 1];
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+      const int d = 32 * dt + 16 * pr + 8 * half;   // lanes 0-31: columns 16pr .. +7, lanes 32-63: 16pr + 8 .. +15
+      if (ok && d < Dh) *(uint4*)(row + d) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+}
+
 // Block -> (row block, (batch, head)) coordinates.  The grid is 1-D; hardware places workgroup L on XCD L % 8, and the row
 // blocks of one (batch, head) pair re-read the same K/V (or Q/dO) tiles, so each XCD is given a contiguous run of the
 // pair-major order: the re-reads then hit that XCD's L2 instead of crossing the fabric once per row block
@@ -116,7 +142,7 @@ __device__ __forceinline__ BlockXY block_xy(int nx) {
 
 // ------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, AttnDims dm) {
+                                                       bf16_t* __restrict__ out_res, float* __restrict__ lse, AttnDims dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -268,21 +294,26 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     run(std::true_type{});
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
-  if (q < N) {
-    bf16_t* orow = out + ((size_t)b * N + q) * ((size_t)dm.H * Dh) + (size_t)h * Dh;
+  {
+    // rounding residual of O (bf16 again): the backward pass forms D = sum_d dO * (O + residual), i.e. from O at ~16 mantissa
+    // bits.  With D from the bf16 O alone its error (2^-9 |O||dO|) does not cancel against dP in dS = P (dP - D) the way it does
+    // in the unfused softmax backward, and where attention is near-uniform (dQ is a small residual of large terms) dQ came out
+    // 20-30 % wrong (tools/debug/attn_insitu.py).
+    uint2 wo[2][4], wr[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int d = 32 * dt + 8 * g + 4 * half;
-        if (d < Dh) {
-          uint2 w;
-          w.x = pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv);
-          w.y = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
-          *(uint2*)(orow + d) = w;
-        }
+        const float v0 = oacc[dt][4 * g] * inv, v1 = oacc[dt][4 * g + 1] * inv, v2 = oacc[dt][4 * g + 2] * inv, v3 = oacc[dt][4 * g + 3] * inv;
+        wo[dt][g].x = pack2bf(v0, v1);
+        wo[dt][g].y = pack2bf(v2, v3);
+        wr[dt][g].x = pack2bf(v0 - __uint_as_float(wo[dt][g].x << 16), v1 - __uint_as_float(wo[dt][g].x & 0xffff0000u));
+        wr[dt][g].y = pack2bf(v2 - __uint_as_float(wo[dt][g].y << 16), v3 - __uint_as_float(wo[dt][g].y & 0xffff0000u));
       }
-    if (lse && half == 0) lse[(size_t)bh * N + q] = (m_run + log2f(l_tot)) * LN2;
+    const size_t ro = ((size_t)b * N + (q < N ? q : 0)) * ((size_t)dm.H * Dh) + (size_t)h * Dh;
+    store_row_groups(out + ro, Dh, half, wo, q < N);
+    if (out_res) store_row_groups(out_res + ro, Dh, half, wr, q < N);
+    if (q < N && lse && half == 0) lse[(size_t)bh * N + q] = (m_run + log2f(l_tot)) * LN2;
   }
 }
 
@@ -291,6 +322,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
 // D[b,h,q] = sum_d dO*O is formed here from the rows this lane already holds (O is one more 16-byte load per chunk)
 // and stored for the dK/dV kernel, which runs after this one: no separate preparation pass.
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                          const bf16_t* __restrict__ ores,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                           float* __restrict__ Dv, bf16_t* __restrict__ dqkv, AttnDims dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
@@ -308,22 +340,25 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
 
   bf16x8 qf[4], dof[4];
   float dsum = 0.f;
+  const bf16_t* rsrc = ores ? ores : o;   // residual of O (absent: O is read a second time and the value dropped)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int d = 16 * s + 8 * half;
-    uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+    uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
     if (q < N && d < Dh) {
       t = *(const uint4*)(qb + (size_t)q * rs + d);
       u = *(const uint4*)(dob + (size_t)q * ors + d);
       ov = *(const uint4*)(o + (size_t)b * N * ors + (size_t)h * Dh + (size_t)q * ors + d);
+      rv = *(const uint4*)(rsrc + (size_t)b * N * ors + (size_t)h * Dh + (size_t)q * ors + d);   // (unconditional: no branch per load)
     }
+    if (!ores) rv = make_uint4(0, 0, 0, 0);
     qf[s] = *(bf16x8*)&t;
     dof[s] = *(bf16x8*)&u;
-    const uint32_t ua[4] = {ov.x, ov.y, ov.z, ov.w}, uc[4] = {u.x, u.y, u.z, u.w};
+    const uint32_t ua[4] = {ov.x, ov.y, ov.z, ov.w}, uc[4] = {u.x, u.y, u.z, u.w}, ur[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      dsum += __uint_as_float(ua[j] << 16) * __uint_as_float(uc[j] << 16);
-      dsum += __uint_as_float(ua[j] & 0xffff0000u) * __uint_as_float(uc[j] & 0xffff0000u);
+      dsum += (__uint_as_float(ua[j] << 16) + __uint_as_float(ur[j] << 16)) * __uint_as_float(uc[j] << 16);
+      dsum += (__uint_as_float(ua[j] & 0xffff0000u) + __uint_as_float(ur[j] & 0xffff0000u)) * __uint_as_float(uc[j] & 0xffff0000u);
     }
   }
   dsum += __shfl_xor(dsum, 32, 64);  // the other half of the head dimension
@@ -421,20 +456,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     run(std::false_type{});
   else
     run(std::true_type{});
-  if (q < N) {
-    bf16_t* orow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * Dh;
+  {
+    uint2 wq[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int d = 32 * dt + 8 * g + 4 * half;
-        if (d < Dh) {
-          uint2 w;
-          w.x = pack2bf(dqacc[dt][4 * g], dqacc[dt][4 * g + 1]);
-          w.y = pack2bf(dqacc[dt][4 * g + 2], dqacc[dt][4 * g + 3]);
-          *(uint2*)(orow + d) = w;
-        }
+        wq[dt][g].x = pack2bf(dqacc[dt][4 * g], dqacc[dt][4 * g + 1]);
+        wq[dt][g].y = pack2bf(dqacc[dt][4 * g + 2], dqacc[dt][4 * g + 3]);
       }
+    store_row_groups(dqkv + ((size_t)b * N + (q < N ? q : 0)) * rs + (size_t)h * Dh, Dh, half, wq, q < N);
   }
 }
 
@@ -573,24 +604,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     run(std::false_type{});
   else
     run(std::true_type{});
-  if (key < N) {
-    bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)(dm.H + h) * Dh;
-    bf16_t* vrow = krow + (size_t)dm.H * Dh;
+  {
+    uint2 wk[2][4], wv[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int d = 32 * dt + 8 * g + 4 * half;
-        if (d < Dh) {
-          uint2 w;
-          w.x = pack2bf(dkacc[dt][4 * g], dkacc[dt][4 * g + 1]);
-          w.y = pack2bf(dkacc[dt][4 * g + 2], dkacc[dt][4 * g + 3]);
-          *(uint2*)(krow + d) = w;
-          w.x = pack2bf(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
-          w.y = pack2bf(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
-          *(uint2*)(vrow + d) = w;
-        }
+        wk[dt][g].x = pack2bf(dkacc[dt][4 * g], dkacc[dt][4 * g + 1]);
+        wk[dt][g].y = pack2bf(dkacc[dt][4 * g + 2], dkacc[dt][4 * g + 3]);
+        wv[dt][g].x = pack2bf(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
+        wv[dt][g].y = pack2bf(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
       }
+    bf16_t* krow = dqkv + ((size_t)b * N + (key < N ? key : 0)) * rs + (size_t)(dm.H + h) * Dh;
+    store_row_groups(krow, Dh, half, wk, key < N);
+    store_row_groups(krow + (size_t)dm.H * Dh, Dh, half, wv, key < N);
   }
 }
 
@@ -598,24 +625,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 extern "C" {
 
-MVIT_API int mvit_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int Dh, float scale,
+MVIT_API int mvit_attention_fwd(const void* qkv, void* out, void* out_res, float* lse, int B, int N, int H, int Dh, float scale,
                                 mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, (hipStream_t)stream,
-                     (const bf16_t*)qkv, (bf16_t*)out, lse, dm);
+                     (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)out_res, lse, dm);
   return MVIT_LAUNCH_CHECK();
 }
 
-MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum,
-                                void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream) {
+MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* out_res, const void* d_out, const float* lse,
+                                float* dsum, void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
   AttnDims dm{B, N, H, Dh, scale};
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
-                     (const bf16_t*)out, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
+                     (const bf16_t*)out, (const bf16_t*)out_res, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;
   static mvit_per_device_size lds_raised;  // grow-only per device: the attribute is a per-function, per-device maximum
   if (mvit_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel, lds_kv, lds_raised) != MVIT_OK) return MVIT_EINVAL;

@@ -61,6 +61,29 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) atomicAdd(out, r);
 }
 
+// ordered variant (deterministic mode): per-block partial sums, then ONE block adds them in index order
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, long long n) {
+  __shared__ double sh[4];
+  double acc = 0.;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 a = *(const float4*)(x + i);
+      acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
+    } else {
+      for (long long j = i; j < n; ++j) acc += (double)x[j] * x[j];
+    }
+  }
+  const double r = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(64) void sqnorm_finish_kernel(const double* __restrict__ partial, int nparts, double* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    double t = 0.;
+    for (int i = 0; i < nparts; ++i) t += partial[i];
+    *out += t;
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, const double* __restrict__ sqnorm, long long n,
                                                    float lr, float b1, float b2, float eps, float bc1, float bc2,
@@ -116,6 +139,15 @@ MVIT_API int mvit_sqnorm(const float* x, double* out, long long n, mvit_stream_t
   MVIT_CLEAR_ERROR();
   if (n <= 0) return MVIT_EINVAL;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk(n, 1024 * 16, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_sqnorm_ordered(const float* x, double* out, double* scratch256, long long n, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (n <= 0 || !scratch256 || !out) return MVIT_EINVAL;
+  const int nb = nblk(n, 1024 * 16, 256);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, scratch256, n);
+  hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch256, nb, out);
   return MVIT_LAUNCH_CHECK();
 }
 

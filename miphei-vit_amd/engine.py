@@ -55,6 +55,7 @@ class HipEngine:
         self._opt_stash = None       # Adam state carried across re-flattening (see invalidate)
         self._nonfinite = None       # device int32: sticky NaN-guard flag written by the Adam kernel
         self.lora_group = 10         # ViT blocks whose LoRA weight-gradient products share one launch (_encoder_bwd)
+        self.use_chunked_conv = True  # fusion blocks 0-2 on the chunked direct convolution (False: implicit GEMM, for A/B runs)
         self.invalidate()
 
     # ------------------------------------------------------------------ state management
@@ -317,6 +318,7 @@ class HipEngine:
         convs = [cv for cv in dec.convstream.convs] + [fb.conv for fb in dec.fusion_blks]
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
         pk.wdir_f = pk.wdir_b = None
+        pk.wch_f, pk.wch_b = {}, {}          # fusion blocks 0-2: operands of the chunked direct convolution (forward / input gradient)
         packs = []
         for i, cv in enumerate(convs):
             w = f32(cv.conv.weight).contiguous()                                    # [Cout, Cin, 3, 3]
@@ -324,9 +326,18 @@ class HipEngine:
             last = i == len(convs) - 1                                              # fus3: internal order [up(64) | img(3)]
             perm = torch.cat([torch.arange(3, cin), torch.arange(0, 3)]).to(dev) if last else None
             cp = _pad8(cin)
-            wk = torch.empty(cout, 9 * cp, device=dev, dtype=bf)
-            wd = torch.empty(cp, 9 * cout, device=dev, dtype=bf) if need_bwd else None
-            packs.append((w, wk, wd, 3 if last else 0))
+            chunked = self.use_chunked_conv and 3 <= i < len(convs) - 1 and cin % 8 == 0 and cout % 8 == 0
+            if chunked:
+                # wide fusion blocks (1728 -> 256, 352 -> 128, 176 -> 64): direct convolution on LDS-staged tiles, input channels in
+                # chunks of 32, output channels in slices of 64 (csrc/conv_chunked.hip); no implicit-GEMM weight layouts needed
+                pk.wch_f[i] = ops.pack_conv3x3_chunked(w)
+                if need_bwd:
+                    pk.wch_b[i] = ops.pack_conv3x3_chunked(w, dgrad=True)
+                wk = wd = None
+            else:
+                wk = torch.empty(cout, 9 * cp, device=dev, dtype=bf)
+                wd = torch.empty(cp, 9 * cout, device=dev, dtype=bf) if need_bwd else None
+                packs.append((w, wk, wd, 3 if last else 0))
             pk.wk.append(wk)
             if need_bwd:
                 pk.wd.append(wd)
@@ -339,7 +350,7 @@ class HipEngine:
             pk.cin.append(cin)
             pk.cin_pad.append(cp)
             pk.perm.append(perm)
-        ops.pack_conv3x3_weights_multi(packs)      # all seven in one launch
+        ops.pack_conv3x3_weights_multi(packs)      # all implicit-GEMM layouts in one launch
         heads = self._heads()
         st = lambda get, shape: torch.stack([f32(get(h)).reshape(-1) for h in heads]).reshape(shape).contiguous()
         NH = c.NH
@@ -384,6 +395,7 @@ class HipEngine:
         w.t = list(w.t_all.unbind(0)) if c.lora else None
         w.qkv = [e(M, 3 * D) for _ in range(nl)]
         w.o = [e(M, D) for _ in range(nl)]
+        w.ores = [e(M, D) for _ in range(nl)] if train else None   # bf16 rounding residual of o (D term of the attention backward)
         w.lse = [e(B, c.H, c.ntok, dt=torch.float32) for _ in range(nl)]
         w.u = [e(M, c.hidden) for _ in range(nl)] if train else None
         w.g = e(M, c.Hg)
@@ -527,7 +539,7 @@ class HipEngine:
             else:
                 ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
-            ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale)
+            ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[i] if train else None)
             ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32,
                      rowscale=None if dp is None else dp[l, 0])
             ops.layernorm_fwd(xmid, b.n2w, b.n2b, w.h2, c.eps)
@@ -591,6 +603,9 @@ class HipEngine:
             if j == 3 and pk.wdir_f is not None and cat.numel() * 2 < 2 ** 31:    # (32-bit byte offsets of its raw buffer)
                 ops.conv3x3_direct(cat, pk.wdir_f, w.pre_f[j], B=B, H=r, W=r, cin_pad=cp, ldx=cp, cout=FUS_OUT[j], ldy=FUS_OUT[j],
                                    stats=w.stats_f[i] if bn_train else None, nslots=NSLOTS)
+            elif i in pk.wch_f and cat.numel() * 2 < 2 ** 31:
+                ops.conv3x3_chunked(cat, pk.wch_f[i], w.pre_f[j], B=B, H=r, W=r, cin=cp, ldx=cp, cout=FUS_OUT[j], ldy=FUS_OUT[j],
+                                    stats=w.stats_f[i] if bn_train else None, nslots=NSLOTS)
             elif bn_train:
                 ops.gemm(cat, pk.wk[i], w.pre_f[j], M=Mo, amode=A_CONV3, conv=(r, r, cp, cp, r, r, 1), epi=EPI_STATS,
                          stats=w.stats_f[i], nslots=NSLOTS)
@@ -738,6 +753,8 @@ class HipEngine:
             if j == 3 and pk.wdir_b is not None and w.dpre_f[j].numel() * 2 < 2 ** 31:
                 ops.conv3x3_direct(w.dpre_f[j], pk.wdir_b, dcat, B=B, H=r, W=r, cin_pad=cout, ldx=cout, cout=ncols,
                                    ldy=dcat.shape[-1])
+            elif i in pk.wch_b and w.dpre_f[j].numel() * 2 < 2 ** 31:
+                ops.conv3x3_chunked(w.dpre_f[j], pk.wch_b[i], dcat, B=B, H=r, W=r, cin=cout, ldx=cout, cout=ncols, ldy=dcat.shape[-1])
             else:
                 ops.gemm(w.dpre_f[j], pk.wd[i], dcat, M=Mo, N=ncols, amode=A_CONV3_T, conv=(r, r, cout, cout, r, r, 1),
                          ldc=dcat.shape[-1])
@@ -815,7 +832,7 @@ class HipEngine:
             # attention branch: dy = ls1 * dx
             ops.gemm(w.dy, b.t.wproj, w.do)
             dqkv, dt = w.dqkv_all[l], w.dt_all[l]
-            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, dqkv, B, c.ntok, c.H, c.Dh, scale)
+            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, dqkv, B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[l])
             dq, dv = dqkv, dqkv.view(-1)[2 * D:]
             # dt_q = dq @ (a B_q)^T, dt_v = dv @ (a B_v)^T: one launch
             ops.skinny_xw2(dq, pk.Bq16[l], dt, dv, pk.Bv16[l], dt.view(-1)[r_:], ldx=3 * D, ldw=D, ldo=2 * r_, M=M, K=D, R=r_)

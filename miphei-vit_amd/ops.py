@@ -278,8 +278,9 @@ def _kprobed(key, flops, name, *args):
     KPROBE.add(key, e0, e1, flops)
 
 
-def attention_fwd(qkv, out, lse, B, N, H, Dh, scale):
-    args = (_p(qkv), _p(out), _p(lse), B, N, H, Dh, scale)
+def attention_fwd(qkv, out, lse, B, N, H, Dh, scale, out_res=None):
+    """out_res (bf16, like out; training): receives the rounding residual of out for the backward pass's D term"""
+    args = (_p(qkv), _p(out), _p(out_res), _p(lse), B, N, H, Dh, scale)
     if KPROBE.on:       # algorithmic FLOPs: S = QK^T and O = PV, 2 * 2 * N^2 * Dh per (batch, head)
         _kprobed("attn_fwd_kernel", 4.0 * B * H * N * N * Dh, "mvit_attention_fwd", *args)
     else:
@@ -287,8 +288,8 @@ def attention_fwd(qkv, out, lse, B, N, H, Dh, scale):
     return out
 
 
-def attention_bwd(qkv, out, d_out, lse, dsum, dqkv, B, N, H, Dh, scale):
-    args = (_p(qkv), _p(out), _p(d_out), _p(lse), _p(dsum), _p(dqkv), B, N, H, Dh, scale)
+def attention_bwd(qkv, out, d_out, lse, dsum, dqkv, B, N, H, Dh, scale, out_res=None):
+    args = (_p(qkv), _p(out), _p(out_res), _p(d_out), _p(lse), _p(dsum), _p(dqkv), B, N, H, Dh, scale)
     if KPROBE.on:       # algorithmic FLOPs of the backward: dV, dP, dQ, dK + the recomputed S = 5 products (2.5 x fwd)
         _kprobed("attn_bwd (all launches of mvit_attention_bwd)", 10.0 * B * H * N * N * Dh, "mvit_attention_bwd", *args)
     else:
@@ -418,6 +419,28 @@ def conv3x3_direct(x, wp, y, *, B, H, W, cin_pad, ldx, cout, ldy, stats=None, ns
     return y
 
 
+def pack_conv3x3_chunked(W, dgrad=False):
+    """nn.Conv2d weight [Cout,Cin,3,3] f32 -> operand of mvit_conv3x3_chunked ([slices][chunks][9][64][40] bf16);
+    dgrad=True: the adjoint convolution (k = output channel of the forward conv, n = its input channel, taps flipped)."""
+    assert W.dtype == torch.float32 and W.is_contiguous()
+    cout, cin = W.shape[0], W.shape[1]
+    n, k = (cin, cout) if dgrad else (cout, cin)
+    out = torch.empty(int(L.lib().mvit_conv3x3_chunked_pack_elems(n, k)), device=W.device, dtype=torch.bfloat16)
+    _call("mvit_conv3x3_chunked_pack", _p(W), _p(out), cout, cin, int(dgrad))
+    return out
+
+
+def conv3x3_chunked(x, wp, y, *, B, H, W, cin, ldx, cout, ldy, stats=None, nslots=0):
+    """y[b,h,w,:cout] = conv3x3(x[b,h,w,:cin]) (stride 1, pad 1, NHWC bf16): LDS-staged tiles, 32-channel chunks, 64-channel slices"""
+    _chk_bf16(x, "x")
+    _chk_bf16(wp, "wp")
+    _chk_bf16(y, "y")
+    if stats is not None:
+        assert stats.dtype == torch.float64
+    _call("mvit_conv3x3_chunked", _p(x), _p(wp), _p(y), _p(stats), nslots, B, H, W, cin, ldx, cout, ldy)
+    return y
+
+
 def pixel_shuffle2x(packed, img, B, H, W, C_, ld_img, inverse=False):
     _call("mvit_pixel_shuffle2x", _p(packed), _p(img), B, H, W, C_, ld_img, int(inverse))
 
@@ -478,8 +501,18 @@ def wmse_fwd_bwd(pred, target, w, loss_acc, dY, lambda_factor):
     _call("mvit_wmse_fwd_bwd", _p(pred), _p(target), _p(w), _p(loss_acc), _p(dY), B, Cc, H * W, lambda_factor)
 
 
+_sqn_scratch = {}
+
+
 def sqnorm(x, out):
-    _call("mvit_sqnorm", _p(x), _p(out), x.numel())
+    """out (f64 scalar) += sum x^2; in the deterministic mode through the ordered two-launch variant"""
+    if DETERMINISTIC:
+        scr = _sqn_scratch.get(x.device)
+        if scr is None:
+            scr = _sqn_scratch[x.device] = torch.empty(256, device=x.device, dtype=torch.float64)
+        _call("mvit_sqnorm_ordered", _p(x), _p(out), _p(scr), x.numel())
+    else:
+        _call("mvit_sqnorm", _p(x), _p(out), x.numel())
 
 
 def adam_clip_step(p, g, m, v, sqn, lr, beta1, beta2, eps, bc1, bc2, max_norm, nonfinite=None):

@@ -153,7 +153,7 @@ layer_norm.register_autograd(_ln_bwd, setup_context=_ln_setup)
 
 # ------------------------------------------------------------------ attention
 @torch.library.custom_op("mvit::attention_forward", mutates_args=(), device_types="cuda")
-def attention_forward(qkv: Tensor, num_heads: int) -> tuple[Tensor, Tensor]:
+def attention_forward(qkv: Tensor, num_heads: int) -> tuple[Tensor, Tensor, Tensor]:
     B, N, C3 = qkv.shape
     D = C3 // 3
     Dh = D // num_heads
@@ -162,29 +162,32 @@ def attention_forward(qkv: Tensor, num_heads: int) -> tuple[Tensor, Tensor]:
     q = (qkv if qkv.dtype == _BF else qkv.to(_BF)).contiguous()
     out = torch.empty(B, N, D, device=qkv.device, dtype=_BF)
     lse = torch.empty(B, num_heads, N, device=qkv.device, dtype=torch.float32)
-    ops.attention_fwd(q, out, lse, B, N, num_heads, Dh, Dh ** -0.5)
-    return out, lse
+    res = torch.empty_like(out)       # bf16 rounding residual of out: the backward pass's D term (see include/miphei_hip.h)
+    ops.attention_fwd(q, out, lse, B, N, num_heads, Dh, Dh ** -0.5, out_res=res)
+    return out, lse, res
 
 
 @attention_forward.register_fake
 def _(qkv, num_heads):
     B, N, C3 = qkv.shape
-    return qkv.new_empty(B, N, C3 // 3, dtype=_BF), qkv.new_empty(B, num_heads, N, dtype=torch.float32)
+    return (qkv.new_empty(B, N, C3 // 3, dtype=_BF), qkv.new_empty(B, num_heads, N, dtype=torch.float32),
+            qkv.new_empty(B, N, C3 // 3, dtype=_BF))
 
 
 @torch.library.custom_op("mvit::attention_backward", mutates_args=(), device_types="cuda")
-def attention_backward(grad: Tensor, qkv: Tensor, out: Tensor, lse: Tensor, num_heads: int) -> Tensor:
+def attention_backward(grad: Tensor, qkv: Tensor, out: Tensor, lse: Tensor, out_res: Tensor, num_heads: int) -> Tensor:
     B, N, C3 = qkv.shape
     Dh = C3 // 3 // num_heads
     q = (qkv if qkv.dtype == _BF else qkv.to(_BF)).contiguous()
     dqkv = torch.empty_like(q)
     dsum = torch.empty(B, num_heads, N, device=qkv.device, dtype=torch.float32)
-    ops.attention_bwd(q, out, (grad if grad.dtype == _BF else grad.to(_BF)).contiguous(), lse, dsum, dqkv, B, N, num_heads, Dh, Dh ** -0.5)
+    ops.attention_bwd(q, out, (grad if grad.dtype == _BF else grad.to(_BF)).contiguous(), lse, dsum, dqkv, B, N, num_heads, Dh, Dh ** -0.5,
+                      out_res=out_res)
     return dqkv.to(qkv.dtype)
 
 
 @attention_backward.register_fake
-def _(grad, qkv, out, lse, num_heads):
+def _(grad, qkv, out, lse, out_res, num_heads):
     return torch.empty_like(qkv)
 
 
@@ -195,15 +198,15 @@ def attention(qkv: Tensor, num_heads: int) -> Tensor:
 
 def _attn_setup(ctx, inputs, output):
     qkv, num_heads = inputs
-    out, lse = output
-    ctx.save_for_backward(qkv, out, lse)
+    out, lse, res = output
+    ctx.save_for_backward(qkv, out, lse, res)
     ctx.num_heads = num_heads
-    ctx.mark_non_differentiable(lse)
+    ctx.mark_non_differentiable(lse, res)
 
 
-def _attn_bwd(ctx, grad_out, _grad_lse):
-    qkv, out, lse = ctx.saved_tensors
-    return torch.ops.mvit.attention_backward(grad_out.contiguous(), qkv, out, lse, ctx.num_heads), None
+def _attn_bwd(ctx, grad_out, _grad_lse, _grad_res):
+    qkv, out, lse, res = ctx.saved_tensors
+    return torch.ops.mvit.attention_backward(grad_out.contiguous(), qkv, out, lse, res, ctx.num_heads), None
 
 
 attention_forward.register_autograd(_attn_bwd, setup_context=_attn_setup)

@@ -33,7 +33,9 @@ class DataParallelSync:
         self.lora_buckets = max(1, int(lora_buckets))
         self.timing = timing
         self.exposed_events = []
+        self.bucket_events = []       # timing: per step [(bytes, issue event, finish-start event, wait-done event), ...] in issue order
         self._work = []
+        self._issued = []
         self._ranges = None
 
     def _buffers(self, kind):
@@ -52,6 +54,10 @@ class DataParallelSync:
 
     def _issue(self, t):
         if t.numel():
+            if self.timing and t.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()                       # on the compute stream, at the point of the backward pass that releases the bucket
+                self._issued.append((t.numel() * t.element_size(), ev))
             self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def decoder_ready(self):
@@ -84,8 +90,16 @@ class DataParallelSync:
         if self.timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        marks = []
         for wk in self._work:
             wk.wait()
+            if self.timing and self._issued:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+        if self.timing and self._issued and len(marks) == len(self._issued):
+            self.bucket_events.append([(nb, iss, e0, mk) for (nb, iss), mk in zip(self._issued, marks)])
+        self._issued = []
         self._work = []
         if self.world > 1:
             for buf in self._buffers("grad"):
@@ -102,6 +116,26 @@ class DataParallelSync:
         ms = [a.elapsed_time(b) for a, b in self.exposed_events]
         self.exposed_events = []
         return sum(ms) / len(ms)
+
+
+    def bucket_report(self):
+        """Per bucket (issue order: decoder, then the LoRA sub-buckets), averaged over the timed steps: bytes, ``slack_ms`` = time
+        between the bucket's issue inside the backward pass and the start of ``finish`` (what the exchange could hide behind) and
+        ``wait_ms`` = how long the compute stream then stalled for it (cumulative waits: bucket k's stall starts where bucket
+        k-1's ended).  Explains a scaling number: efficiency is lost exactly where wait_ms is not ~0."""
+        if not self.bucket_events:
+            return None
+        torch.cuda.synchronize()
+        n = len(self.bucket_events[0])
+        steps = [st for st in self.bucket_events if len(st) == n]
+        out = []
+        for k in range(n):
+            slack = [st[k][1].elapsed_time(st[k][2]) for st in steps]
+            wait = [(st[k - 1][3] if k else st[k][2]).elapsed_time(st[k][3]) for st in steps]
+            out.append({"bytes": int(steps[0][k][0]), "slack_ms": round(sum(slack) / len(slack), 4),
+                        "wait_ms": round(sum(wait) / len(wait), 4)})
+        self.bucket_events = []
+        return out
 
 
 def allreduce_mean_(flat, world, group=None):

@@ -100,3 +100,47 @@ def test_direct_conv_rejects_unsupported_shapes():
     x = torch.zeros(1, 8, 8, 176, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         ops.conv3x3_direct(x, x, x, B=1, H=8, W=8, cin_pad=176, ldx=176, cout=64, ldy=176)
+
+
+# (B, H, W, Cin, ldx, Cout): the three wide MIPHEI fusion layers at batch 2 (1728 -> 256 @ 32^2, 352 -> 128 @ 64^2, 176 -> 64 @
+# 128^2), ragged image sizes, a channel count that ends inside a 32-channel chunk and inside a 64-channel slice, a wider buffer
+@pytest.mark.parametrize("B,H,W,cin,ldx,cout", [(2, 32, 32, 1728, 1728, 256), (2, 64, 64, 352, 352, 128), (2, 128, 128, 176, 176, 64),
+                                                (3, 37, 45, 40, 48, 72), (1, 9, 70, 24, 24, 8), (2, 16, 32, 96, 96, 200)])
+def test_chunked_conv_forward_stats_and_input_gradient(B, H, W, cin, ldx, cout):
+    """csrc/conv_chunked.hip against F.conv2d on the same bf16-rounded operands: forward with BatchNorm statistics (and without),
+    against the implicit-GEMM convolution it replaces, and the input gradient through the adjoint packing against autograd."""
+    import miphei_vit_amd.ops as ops
+    w = _rand(cout, cin, 3, 3, seed=1, scale=(9 * cin) ** -0.5)
+    x = _rand(B, H, W, cin, seed=2).bfloat16()
+    xb = torch.full((B, H, W, ldx), 3.0, device="cuda", dtype=torch.bfloat16)      # garbage beyond the used channels (ldx > cin)
+    xb[..., :cin] = x
+    wp = ops.pack_conv3x3_chunked(w)
+    ldy = cout + 8
+    y = torch.full((B, H, W, ldy), 5.0, device="cuda", dtype=torch.bfloat16)
+    nslots = 256
+    stats = torch.zeros(nslots * 2 * cout, device="cuda", dtype=torch.float64)
+    ops.conv3x3_chunked(xb, wp, y, B=B, H=H, W=W, cin=cin, ldx=ldx, cout=cout, ldy=ldy, stats=stats, nslots=nslots)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), padding=1).permute(0, 2, 3, 1)
+    assert _rel(y[..., :cout].float(), ref) < 4e-3
+    assert float((y[..., :cout].float() - ref).abs().max()) < 0.05 * float(ref.abs().max()) + 0.02      # no misplaced tile / chunk
+    assert bool((y[..., cout:] == 5.0).all())
+    st = stats.view(nslots, 2, cout).sum(0)
+    assert _rel(st[0], ref.double().sum((0, 1, 2))) < 1e-4 + 2e-3 and _rel(st[1], (ref.double() ** 2).sum((0, 1, 2))) < 1e-4
+    y3 = torch.empty_like(y)
+    ops.conv3x3_chunked(xb, wp, y3, B=B, H=H, W=W, cin=cin, ldx=ldx, cout=cout, ldy=ldy)
+    assert torch.equal(y3[..., :cout], y[..., :cout])
+    if ldx == cin:      # the implicit-GEMM convolution of the same layer
+        wk = torch.empty(cout, 9 * cin, device="cuda", dtype=torch.bfloat16)
+        ops.pack_conv3x3_weights(w, wk, None, rot=0)
+        y2 = torch.empty(B * H * W, cout, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(xb, wk, y2, M=B * H * W, amode=ops.A_CONV3, conv=(H, W, cin, cin, H, W, 1))
+        assert _rel(y[..., :cout].float().reshape(-1, cout), y2.float()) < 3e-3
+    # input gradient: dX[b, y, x, ci] from dY through the flipped / transposed weights
+    dy = _rand(B, H, W, cout, seed=3).bfloat16()
+    wpb = ops.pack_conv3x3_chunked(w, dgrad=True)
+    dx = torch.full((B, H, W, cin + 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.conv3x3_chunked(dy, wpb, dx, B=B, H=H, W=W, cin=cout, ldx=cout, cout=cin, ldy=cin + 8)
+    xx = torch.zeros(B, cin, H, W, device="cuda", requires_grad=True)
+    F.conv2d(xx, w.bfloat16().float(), padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    assert _rel(dx[..., :cin].float(), xx.grad.permute(0, 2, 3, 1)) < 4e-3
+    assert bool((dx[..., cin:] == 7.0).all())

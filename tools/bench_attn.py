@@ -20,10 +20,14 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-f = t(lambda: ops.attention_fwd(qkv, out, lse, B, N, H, Dh, sc))
-b = t(lambda: ops.attention_bwd(qkv, out, dO, lse, dsum, dqkv, B, N, H, Dh, sc))
+res = torch.empty_like(out)
+f0 = t(lambda: ops.attention_fwd(qkv, out, lse, B, N, H, Dh, sc))
+f = t(lambda: ops.attention_fwd(qkv, out, lse, B, N, H, Dh, sc, out_res=res))
+b0 = t(lambda: ops.attention_bwd(qkv, out, dO, lse, dsum, dqkv, B, N, H, Dh, sc))
+b = t(lambda: ops.attention_bwd(qkv, out, dO, lse, dsum, dqkv, B, N, H, Dh, sc, out_res=res))
 fl = 4.0 * B * H * N * N * Dh
-print(f"N={N} fwd {f*1e3:.1f} us ({fl/f/1e9:.1f} TF/s)   bwd {b*1e3:.1f} us ({2.5*fl/b/1e9:.1f} TF/s useful)")
+print(f"N={N} fwd {f*1e3:.1f} us ({fl/f/1e9:.1f} TF/s; {f0*1e3:.1f} us without the O residual)   "
+      f"bwd {b*1e3:.1f} us ({2.5*fl/b/1e9:.1f} TF/s useful; {b0*1e3:.1f} us without)")
 if len(sys.argv) > 2 and sys.argv[2] == "ours":
     sys.exit(0)
 # yardstick: the vendor attention behind torch SDPA (CK / AOTriton flash attention) on the same problem

@@ -52,5 +52,13 @@ for name, r_in, cp, r_out, cout, stride in layers:
     ms = max(1, min(1024 // tiles, (Mo + 255) // 256))
     dwt = torch.zeros(K9, cout, device="cuda")
     t_w = timeit(lambda: ops.gemm_tn(x, dy, dwt, M=Mo, I=K9, J=cout, ldb=cout, ldci=cout, msplit=ms, conv=(r_in, r_in, cp, cp, r_out, r_out, stride)))
-    print(f"{name}: {gf:6.1f} GF | fwd {t_f:7.1f} us {gf / t_f * 1e-3:5.2f} PF | dgrad {t_d:7.1f} us {gf / t_d * 1e-3:5.2f} PF | "
-          f"wgrad {t_w:7.1f} us {gf / t_w * 1e-3:5.2f} PF (msplit {ms})", flush=True)
+    line = (f"{name}: {gf:6.1f} GF | fwd {t_f:7.1f} us {gf / t_f:5.2f} PF | dgrad {t_d:7.1f} us {gf / t_d:5.2f} PF | "
+            f"wgrad {t_w:7.1f} us {gf / t_w:5.2f} PF (msplit {ms})")
+    if stride == 1 and cp % 8 == 0 and cout % 8 == 0:
+        w4 = torch.randn(cout, cp, 3, 3, device="cuda") * 0.05
+        wf, wb = ops.pack_conv3x3_chunked(w4), ops.pack_conv3x3_chunked(w4, dgrad=True)
+        t_cf = timeit(lambda: ops.conv3x3_chunked(x, wf, y, B=B, H=r_in, W=r_in, cin=cp, ldx=cp, cout=cout, ldy=cout, stats=st, nslots=ops.STAT_SLOTS))
+        t_cd = timeit(lambda: ops.conv3x3_chunked(dy, wb, dx, B=B, H=r_in, W=r_in, cin=cout, ldx=cout, cout=cp, ldy=cp))
+        t_pk = timeit(lambda: ops.pack_conv3x3_chunked(w4))
+        line += f" | chunked fwd {t_cf:7.1f} us {gf / t_cf:5.2f} PF, dgrad {t_cd:7.1f} us {gf / t_cd:5.2f} PF, pack {t_pk:5.1f} us"
+    print(line, flush=True)
