@@ -6,7 +6,7 @@ A step = one ModelModule.training_step on one synthetic minibatch per rank: HIP 
 encoder with LoRA + ViTMatte decoder, bf16 MFMA / f32 accumulate), fused WeightedMSE, HIP backward, gradient
 all-reduce (RCCL) when N>1, global-norm clip + Adam.  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the instantiation with the
-largest share of the step in profiles/r02_kernel_stats_train.txt: the 8-wave 256x128 MFMA GEMM with the plain store
+largest share of the step in profiles/r03_kernel_stats_train.txt: the 8-wave 256x128 MFMA GEMM with the plain store
 epilogue -- qkv forward and the dgrad GEMMs; algorithmic flops / HIP-event durations recorded live during the timed
 steps), `roofline_step` (whole step, algorithmic FLOPs of SURVEY.md 8d / wall time) and `cpu_baseline` (the CPU oracle =
 port of the reference arithmetic, timed on this host's cores on a bounded sample: 2 warm-ups + median of 5).
@@ -62,6 +62,8 @@ def parse_args(argv=None):
                     "reference (models.py:140-143); the headline number is taken with it off (SURVEY.md section 6)")
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
     ap.add_argument("--probe", type=int, default=1, help="0: no HIP-event probe of the dominant kernel (no `roofline` object)")
+    ap.add_argument("--chunked-conv", type=int, default=1, help="0: wide fusion blocks on the implicit GEMM (A/B of csrc/conv_chunked.hip)")
+    ap.add_argument("--attn-residual", type=int, default=1, help="0: attention backward forms D from the bf16 output alone (A/B)")
     ap.add_argument("--lora-group", type=int, default=0, help="ViT blocks per batched LoRA weight-gradient launch (0 = engine default)")
     ap.add_argument("--lora-buckets", type=int, default=4, help="sub-buckets of the LoRA gradient all-reduce (N > 1)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL; gloo only with --dry")
@@ -214,6 +216,8 @@ def main(argv=None):
             model = get_vitmatte("tiny" if a.mode == "embed" else a.encoder, a.img, nc, use_lora=True, pretrained=False)
     synthetic_init_(model, seed=0)
     eng = model._engine
+    if hasattr(eng, "use_chunked_conv"):
+        eng.use_chunked_conv, eng.attn_residual = bool(a.chunked_conv), bool(a.attn_residual)
     if a.lora_group > 0:
         (eng._encoder_engine() if hasattr(eng, "_encoder_engine") else eng).lora_group = a.lora_group
     if unet and not hasattr(eng, "capture_inference"):
@@ -381,7 +385,7 @@ def pmc_traffic():
     inside the timed run: the value is the committed rocprofv3 summary of this same command (separate FETCH_SIZE / WRITE_SIZE
     passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of MI355X_MICROARCH.md; L2-side fabric requests, so
     Infinity-Cache hits are included), newest round first.  (None, None) when no summary is present."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 k = json.load(f)["kernels"]

@@ -294,6 +294,13 @@ MVIT_API long long mvit_conv3x3_chunked_pack_elems(int N, int K);
 MVIT_API int mvit_conv3x3_chunked_pack(const float* W, void* out_bf16, int Cout, int Cin, int mode, mvit_stream_t stream);
 MVIT_API int mvit_conv3x3_chunked(const void* X, const void* Wp, void* Y, double* stats, int nslots, int B, int H, int W, int Cin,
                                   int ldx, int Cout, int ldy, mvit_stream_t stream);
+/* Weight gradient of the same layers on the same staging: dWn(f32)[Cout][9 * Cin_pad] += sum over pixels of
+ * dY[pixel][n] * X[pixel + (ky-1, kx-1)][c] (output-channel major, k = tap * Cin_pad + c: the layout mvit_unpack_conv3x3_wgrad
+ * takes with n_major = 1).  A block owns one (64-channel output slice, 32-channel input chunk) pair and walks a group of tiles with
+ * the nine [32 x 32] tap blocks of each wave in registers; one tile group per pair when there are >= CU-count pairs (single writer
+ * per element), otherwise groups meet in f32 atomics (the host's deterministic mode uses mvit_gemm_tn_bf16 instead). */
+MVIT_API int mvit_conv3x3_chunked_wgrad(const void* X, const void* dY, float* dWn, int B, int H, int W, int Cin, int Cin_pad, int ldx,
+                                        int Cout, int ldy, mvit_stream_t stream);
 
 /* ---------------------------------------------------------------- per-step operand packs of the trainable tensors */
 /* LoRA adapters (src/generators/lora.py:8-33) from the flat f32 parameter region `lora` = L x [Aq [D,r] | Bq [r,D] | Av | Bv]

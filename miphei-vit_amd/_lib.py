@@ -60,6 +60,7 @@ SIGNATURES = {
     "mvit_conv3x3_chunked_pack_elems": [ci, ci],
     "mvit_conv3x3_chunked_pack": [vp, vp, ci, ci, ci, vp],
     "mvit_conv3x3_chunked": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "mvit_conv3x3_chunked_wgrad": [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_pack_conv3x3_direct": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_lora_pack": [vp, vp, vp, vp, vp, ci, ci, ci, cf, vp],
     "mvit_unpack_conv3x3_wgrad": [vp, vp, ci, ci, ci, ci, ci, ci, vp],

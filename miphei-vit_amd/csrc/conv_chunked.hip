@@ -209,6 +209,162 @@ __global__ __launch_bounds__(256) void conv3x3_chunked_kernel(const CcArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ weight gradient of the wide layers
+// dWn[n][(ky,kx,c)] += sum_pixels dY[pixel][n] * X[pixel + (ky-1, kx-1)][c]   (f32; output-channel major, Cin_pad per tap)
+// A block owns ONE (64-channel output slice, 32-channel input chunk) pair and walks a group of 8 x 32-pixel tiles: per tile it
+// stages the chunk's halo tile of X (21.8 KB) and the slice's dY tile (32 KB) in a two-slot LDS ring, and its 8 waves -- wave =
+// (output-channel tile of 32, quarter of the tile's pixels) -- keep the nine [32 x 32] tap blocks of their quarter in registers
+// (144 accumulators) over ALL tiles of the block.  The contraction runs over pixels, so both MFMA operands are gathered with the
+// transposing LDS read (ds_read_b64_tr_b16), as in conv_direct.hip's weight-gradient kernel.  At the end the four pixel quarters
+// are added in quarter order through LDS and the block adds its [9][64][32] result to the output: with one tile group per pair
+// (the 1728 -> 256 layer: 216 pairs) every element has a single writer; otherwise groups meet in f32 atomics.
+typedef short v4s_cc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 cc_join(v4s_cc a, v4s_cc b) {
+  union { struct { v4s_cc lo, hi; } s; bf16x8 v; } u;
+  u.s.lo = a;
+  u.s.hi = b;
+  return u.v;
+}
+// 4 consecutive rows (stride `rs` bytes) x this lane's column: lane i of a 16-lane group addresses row i>>2, columns 4*(i&3)..+3
+// and receives column i of the 4 x 16 block
+__device__ __forceinline__ v4s_cc cc_tr4(const char* base, int rs, int col16, int lane) {
+  const int i = lane & 15;
+  const char* q = base + (i >> 2) * rs + (col16 + 4 * (i & 3)) * 2;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_cc*)q);
+}
+
+constexpr int CW_THREADS = 512;
+constexpr int CW_XPIECES = (CC_XUNITS + CW_THREADS - 1) / CW_THREADS;        // 3
+constexpr int CW_XBUF = CW_XPIECES * CW_THREADS * 16;                        // 24576
+constexpr int CW_YBYTES = CC_TH * CC_TW * CC_NS * 2;                         // 32768: dY tile [256 pixels][64 channels]
+constexpr int CW_YPIECES = CW_YBYTES / (CW_THREADS * 16);                    // 4
+constexpr int CW_LDS = 2 * (CW_XBUF + CW_YBYTES);
+static_assert(2 * 9 * 1024 * 4 <= CW_LDS, "the quarter reduction reuses the ring");
+
+struct CwcArgs {
+  const bf16_t* X;     // [B, H, W, ldx], channels [0, Cin)
+  const bf16_t* dY;    // [B, H, W, ldy], channels [0, Cout)
+  float* dWn;          // [Cout][9 * Cin_pad] f32, accumulated into
+  int B, H, W, ldx, ldy, Cin, Cout, Cin_pad, groups;
+};
+
+__global__ __launch_bounds__(CW_THREADS) void conv3x3_chunked_wgrad_kernel(const CwcArgs p) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;                       // 2 x halo tile chunk [340 pixels][32 channels] (plain pixel-major image: tr reads)
+  char* Ys = smem + 2 * CW_XBUF;         // 2 x dY tile [256 pixels][64 channels]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int l31 = lane & 31, half = lane >> 5, sub = (lane >> 4) & 1;
+  const int nt = wave & 1, quarter = wave >> 1;       // output-channel tile of the slice, pixel quarter (two tile rows)
+  const int tiles_x = (p.W + CC_TW - 1) / CC_TW, tiles_y = (p.H + CC_TH - 1) / CC_TH;
+  const int ntiles = p.B * tiles_y * tiles_x;
+  const int nchunk = (p.Cin + CC_CK - 1) / CC_CK, nslice = (p.Cout + CC_NS - 1) / CC_NS;
+  const int npair = nchunk * nslice;
+  const int pair = blockIdx.x % npair, group = blockIdx.x / npair;
+  const int slice = pair / nchunk, chunk = pair - slice * nchunk;
+  auto rsrc = [](const void* ptr) __attribute__((always_inline)) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsX = rsrc(p.X), rsY = rsrc(p.dY);
+
+  auto issue_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int y0 = ty * CC_TH - 1, x0 = tx * CC_TW - 1;
+#pragma unroll
+    for (int i = 0; i < CW_XPIECES; ++i) {
+      const int u = (i * 8 + wave_u) * 64 + lane;
+      const int pix = u / CC_CG, cg = u - pix * CC_CG;
+      const int r = pix / (CC_TW + 2), cc = pix - r * (CC_TW + 2);
+      const int iy = y0 + r, ix = x0 + cc, ch = chunk * CC_CK + cg * 8;
+      const bool ok = u < CC_XUNITS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin;
+      unsigned off = ok ? (unsigned)((((size_t)b * p.H + iy) * p.W + ix) * p.ldx + ch) * 2u : 0x80000000u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(Xs + (size_t)buf * CW_XBUF + (size_t)(i * 8 + wave_u) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CW_YPIECES; ++i) {
+      const int u = (i * 8 + wave_u) * 64 + lane;           // 16-byte unit of the dY tile: pixel u / 8, channel group u % 8
+      const int pix = u >> 3, cg = u & 7;
+      const int oy = ty * CC_TH + pix / CC_TW, ox = tx * CC_TW + pix % CC_TW, ch = slice * CC_NS + cg * 8;
+      const bool ok = oy < p.H && ox < p.W && ch < p.Cout;   // pixels outside the image / channels beyond Cout: zero gradient
+      unsigned off = ok ? (unsigned)((((size_t)b * p.H + oy) * p.W + ox) * p.ldy + ch) * 2u : 0x80000000u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_ptr)(Ys + (size_t)buf * CW_YBYTES + (size_t)(i * 8 + wave_u) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  constexpr int NDMA = CW_XPIECES + CW_YPIECES;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  int t = group;
+  if (t < ntiles) issue_tile(t, 0);
+  int buf = 0;
+  for (; t < ntiles; t += p.groups) {
+    const int tn = t + p.groups;
+    __builtin_amdgcn_s_barrier();
+    if (tn < ntiles) {
+      issue_tile(tn, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* xs = Xs + (size_t)buf * CW_XBUF;
+    const char* ys = Ys + (size_t)buf * CW_YBYTES;
+    // this wave's four K steps: pixels [16 s, 16 s + 16) of the tile, s = 4 * quarter .. + 3 (row s >> 1, columns 16 (s & 1) ..);
+    // K-slot order of the fragments: half 0 -> pixels {0-3, 8-11}, half 1 -> {4-7, 12-15} of the step, for both operands
+    bf16x8 fa[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int s_ = 4 * quarter + k;
+      const char* base = ys + (size_t)(16 * s_ + 4 * half) * (CC_NS * 2);
+      fa[k] = cc_join(cc_tr4(base, CC_NS * 2, 32 * nt + 16 * sub, lane), cc_tr4(base + 8 * CC_NS * 2, CC_NS * 2, 32 * nt + 16 * sub, lane));
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int s_ = 4 * quarter + k;
+        const int prow = (s_ >> 1) + ky, pcol = 16 * (s_ & 1) + kx + 4 * half;
+        const char* base = xs + ((size_t)(prow * (CC_TW + 2) + pcol) * CC_CK) * 2;
+        const bf16x8 fb = cc_join(cc_tr4(base, CC_CK * 2, 16 * sub, lane), cc_tr4(base + 8 * CC_CK * 2, CC_CK * 2, 16 * sub, lane));
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k], fb, acc[tap], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+  // the four pixel quarters of an output-channel tile, added in quarter order through LDS (the ring is free now)
+  __builtin_amdgcn_s_barrier();
+  float* red = (float*)smem;                        // [2 channel tiles][9 taps][16 registers][64 lanes]
+  for (int qd = 0; qd < 4; ++qd) {
+    if (quarter == qd) {
+#pragma unroll
+      for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* q = red + ((size_t)(nt * 9 + a) * 16 + r) * 64 + lane;
+          *q = (qd == 0 ? 0.f : *q) + acc[a][r];
+        }
+    }
+    __syncthreads();
+  }
+  // D[n][c]: column c = lane & 31 of the chunk, row n = (r&3) + 8*(r>>2) + 4*half of the channel tile.  512 threads walk the
+  // 2 x 9 x 1024 sums; consecutive lanes = consecutive input channels = consecutive addresses of the output-channel-major result
+  for (int e = tid; e < 2 * 9 * 1024; e += CW_THREADS) {
+    const int ln = e & 63, r = (e >> 6) & 15, a = (e >> 10) % 9, ntile = e / (9 * 1024);
+    const int c = chunk * CC_CK + (ln & 31), n = slice * CC_NS + ntile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    if (c < p.Cin && n < p.Cout) atomicAdd(p.dWn + (size_t)n * (9 * p.Cin_pad) + a * p.Cin_pad + c, red[e]);
+  }
+}
+
 // nn.Conv2d weight W[Cout][Cin][3][3] (f32) -> [slices][chunks][9][64][40] bf16:
 //   mode 0 (forward):  n = output channel, k = input channel:            W[n][k][ky][kx]
 //   mode 1 (dgrad):    n = input channel of the forward conv, k = its output channel, taps flipped:  W[k][n][2-ky][2-kx]
@@ -267,6 +423,24 @@ MVIT_API int mvit_conv3x3_chunked(const void* X, const void* Wp, void* Y, double
   const long long items = (long long)B * ((H + CC_TH - 1) / CC_TH) * ((W + CC_TW - 1) / CC_TW) * ((Cout + CC_NS - 1) / CC_NS);
   const int blocks = items < mvit_num_cus() ? (int)items : mvit_num_cus();      // one persistent block per CU (LDS)
   hipLaunchKernelGGL(conv3x3_chunked_kernel, dim3(blocks), dim3(256), CC_LDS, (hipStream_t)stream, a);
+  return MVIT_LAUNCH_CHECK();
+}
+
+MVIT_API int mvit_conv3x3_chunked_wgrad(const void* X, const void* dY, float* dWn, int B, int H, int W, int Cin, int Cin_pad, int ldx,
+                                        int Cout, int ldy, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!X || !dY || !dWn || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout & 7) || Cin_pad < Cin ||
+      (ldx & 7) || ldx < Cin || (ldy & 7) || ldy < Cout)
+    return MVIT_EINVAL;
+  if ((size_t)B * H * W * ldx * 2 >= 0x7fffffffull || (size_t)B * H * W * ldy * 2 >= 0x7fffffffull) return MVIT_EINVAL;
+  const int ntiles = B * ((H + CC_TH - 1) / CC_TH) * ((W + CC_TW - 1) / CC_TW);
+  const int npair = ((Cin + CC_CK - 1) / CC_CK) * ((Cout + CC_NS - 1) / CC_NS);
+  int groups = mvit_num_cus() / npair;                 // tile groups per (slice, chunk) pair: one block per CU in total
+  groups = groups < 1 ? 1 : (groups > ntiles ? ntiles : groups);
+  CwcArgs a{(const bf16_t*)X, (const bf16_t*)dY, dWn, B, H, W, ldx, ldy, Cin, Cout, Cin_pad, groups};
+  static mvit_per_device_size raised;
+  if (mvit_ensure_dynamic_lds((const void*)conv3x3_chunked_wgrad_kernel, CW_LDS, raised) != MVIT_OK) return MVIT_EINVAL;
+  hipLaunchKernelGGL(conv3x3_chunked_wgrad_kernel, dim3(npair * groups), dim3(CW_THREADS), CW_LDS, (hipStream_t)stream, a);
   return MVIT_LAUNCH_CHECK();
 }
 

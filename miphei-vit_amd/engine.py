@@ -56,6 +56,7 @@ class HipEngine:
         self._nonfinite = None       # device int32: sticky NaN-guard flag written by the Adam kernel
         self.lora_group = 10         # ViT blocks whose LoRA weight-gradient products share one launch (_encoder_bwd)
         self.use_chunked_conv = True  # fusion blocks 0-2 on the chunked direct convolution (False: implicit GEMM, for A/B runs)
+        self.attn_residual = True     # keep the bf16 rounding residual of the attention output for the backward's D term (A/B switch)
         self.invalidate()
 
     # ------------------------------------------------------------------ state management
@@ -539,7 +540,7 @@ class HipEngine:
             else:
                 ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
-            ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[i] if train else None)
+            ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[i] if (train and self.attn_residual) else None)
             ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32,
                      rowscale=None if dp is None else dp[l, 0])
             ops.layernorm_fwd(xmid, b.n2w, b.n2b, w.h2, c.eps)
@@ -719,6 +720,7 @@ class HipEngine:
         Mp = B * S * S
         w.zbuf.zero_()
         fl.gflat.zero_()
+        w.wgrad_n_major_set = set()      # conv layers whose weight-gradient scratch is output-channel major this step
         dY = dY.to(torch.float32).contiguous()
         # ---- heads
         ops.heads_conv_bwd(dY, w.out, w.F3, w.G, pk.W3k, w.cscr, w.dG, w.dXc, w.dW3, w.db3_slots, B, S, S, c.NH)
@@ -739,13 +741,16 @@ class HipEngine:
             bn = convs[i].bn
             ops.bn_relu_bwd(dy_post, ld_post, w.pre_f[j], bp.scale, bp.shift, bp.mean, bp.rstd, pk.bn[i].w, w.stats_b[i],
                             fl.gview[id(bn.weight)], fl.gview[id(bn.bias)], w.dpre_f[j], Mo, cout, NSLOTS)
-            if j == 3 and pk.wdir_f is not None and cat.numel() * 2 < 2 ** 31 and (cp, cout) == (72, 32) and not ops.DETERMINISTIC:
-                # weight gradient on the LDS-staged tiles as well (output-channel-major scratch, see the unpack below)
+            if (i in pk.wch_f or (j == 3 and self.use_chunked_conv)) and not ops.DETERMINISTIC and cat.numel() * 2 < 2 ** 31 \
+                    and w.dpre_f[j].numel() * 2 < 2 ** 31:
+                # weight gradient on the chunked LDS-staged tiles (output-channel-major scratch, see the unpack below); the last
+                # fusion block (72 -> 32) too: 127 us against 155 us for conv_direct.hip's whole-weight variant
+                ops.conv3x3_chunked_wgrad(cat, w.dpre_f[j], w.dWt[i], B=B, H=r, W=r, cin=cp, cin_pad=cp, ldx=cp, cout=cout, ldy=cout)
+                w.wgrad_n_major_set.add(i)
+            elif j == 3 and pk.wdir_f is not None and cat.numel() * 2 < 2 ** 31 and (cp, cout) == (72, 32) and not ops.DETERMINISTIC:
                 ops.conv3x3_direct_wgrad(cat, w.dpre_f[j], w.dWt[i], B=B, H=r, W=r, cin_pad=cp, ldx=cp, cout=cout, ldy=cout)
-                w.wgrad_n_major = True
+                w.wgrad_n_major_set.add(i)
             else:
-                if j == 3:
-                    w.wgrad_n_major = False
                 self._wgrad(w, i, cat, r, cp, cp, r, 1, w.dpre_f[j], cout)
             # dgrad into the concat-gradient buffer (fus3: only the 64 upsampled channels carry gradient)
             ncols = FUS_OUT[2] if j == 3 else cp
@@ -793,7 +798,7 @@ class HipEngine:
                          conv=(r_out, r_out, cout, cout, r_in, r_in, 2), ldc=tgt.shape[-1], flags=ACCUM_BF16)
         # conv weight gradients: dWt [(ky,kx,c_pad), cout] -> parameter layout [cout, cin, ky, kx]
         ops.unpack_conv3x3_wgrad_multi([(w.dWt[i], fl.gview[id(cv.conv.weight)], pk.cin_pad[i], 3 if pk.perm[i] is not None else 0,
-                                         i == len(convs) - 1 and getattr(w, "wgrad_n_major", False))
+                                         i in w.wgrad_n_major_set)
                                         for i, cv in enumerate(convs)])
         if on_decoder_done is not None:
             on_decoder_done()
@@ -832,7 +837,7 @@ class HipEngine:
             # attention branch: dy = ls1 * dx
             ops.gemm(w.dy, b.t.wproj, w.do)
             dqkv, dt = w.dqkv_all[l], w.dt_all[l]
-            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, dqkv, B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[l])
+            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, dqkv, B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[l] if self.attn_residual else None)
             dq, dv = dqkv, dqkv.view(-1)[2 * D:]
             # dt_q = dq @ (a B_q)^T, dt_v = dv @ (a B_v)^T: one launch
             ops.skinny_xw2(dq, pk.Bq16[l], dt, dv, pk.Bv16[l], dt.view(-1)[r_:], ldx=3 * D, ldw=D, ldo=2 * r_, M=M, K=D, R=r_)

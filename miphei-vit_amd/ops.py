@@ -441,6 +441,14 @@ def conv3x3_chunked(x, wp, y, *, B, H, W, cin, ldx, cout, ldy, stats=None, nslot
     return y
 
 
+def conv3x3_chunked_wgrad(x, dy, dwn, *, B, H, W, cin, cin_pad, ldx, cout, ldy):
+    """dwn [cout, 9*cin_pad] f32 += weight gradient of the stride-1 3x3 convolution (chunked LDS-staged tiles, contraction over pixels)"""
+    _chk_bf16(x, "x")
+    _chk_bf16(dy, "dy")
+    assert dwn.dtype == torch.float32 and dwn.numel() == cout * 9 * cin_pad
+    _call("mvit_conv3x3_chunked_wgrad", _p(x), _p(dy), _p(dwn), B, H, W, cin, cin_pad, ldx, cout, ldy)
+
+
 def pixel_shuffle2x(packed, img, B, H, W, C_, ld_img, inverse=False):
     _call("mvit_pixel_shuffle2x", _p(packed), _p(img), B, H, W, C_, ld_img, int(inverse))
 

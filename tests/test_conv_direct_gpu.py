@@ -144,3 +144,26 @@ def test_chunked_conv_forward_stats_and_input_gradient(B, H, W, cin, ldx, cout):
     F.conv2d(xx, w.bfloat16().float(), padding=1).backward(dy.float().permute(0, 3, 1, 2))
     assert _rel(dx[..., :cin].float(), xx.grad.permute(0, 2, 3, 1)) < 4e-3
     assert bool((dx[..., cin:] == 7.0).all())
+
+
+@pytest.mark.parametrize("B,H,W,cin,ldx,cout", [(2, 32, 32, 1728, 1728, 256), (2, 64, 64, 352, 352, 128), (2, 128, 128, 176, 176, 64),
+                                                (3, 37, 45, 40, 48, 72), (1, 9, 70, 24, 24, 8), (16, 32, 32, 96, 96, 64)])
+def test_chunked_conv_weight_gradient(B, H, W, cin, ldx, cout):
+    """dW on the chunked LDS-staged tiles (contraction over pixels, transposing LDS reads) against autograd of F.conv2d on the
+    same bf16-rounded operands and against the TN-GEMM path it replaces; accumulation into a non-zero buffer; one tile group per
+    (slice, chunk) pair (first case: 4 x 54 pairs) and several groups meeting in atomics (the others)."""
+    import miphei_vit_amd.ops as ops
+    x = _rand(B, H, W, cin, seed=2).bfloat16()
+    xb = torch.full((B, H, W, ldx), 3.0, device="cuda", dtype=torch.bfloat16)
+    xb[..., :cin] = x
+    dy = _rand(B, H, W, cout, seed=3).bfloat16()
+    dwn = torch.full((cout, 9 * cin), 0.5, device="cuda")
+    ops.conv3x3_chunked_wgrad(xb, dy, dwn, B=B, H=H, W=W, cin=cin, cin_pad=cin, ldx=ldx, cout=cout, ldy=cout)
+    wz = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), wz, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    ref = wz.grad.permute(0, 2, 3, 1).reshape(cout, 9 * cin)           # [n][(ky, kx, c)]
+    assert _rel(dwn - 0.5, ref) < 2e-3
+    if ldx == cin:
+        dwt = torch.zeros(9 * cin, cout, device="cuda")
+        ops.gemm_tn(xb, dy.view(-1, cout), dwt, M=B * H * W, I=9 * cin, J=cout, ldb=cout, ldci=cout, msplit=4, conv=(H, W, cin, cin, H, W, 1))
+        assert _rel(dwn - 0.5, dwt.t()) < 2e-3

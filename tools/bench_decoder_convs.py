@@ -60,5 +60,8 @@ for name, r_in, cp, r_out, cout, stride in layers:
         t_cf = timeit(lambda: ops.conv3x3_chunked(x, wf, y, B=B, H=r_in, W=r_in, cin=cp, ldx=cp, cout=cout, ldy=cout, stats=st, nslots=ops.STAT_SLOTS))
         t_cd = timeit(lambda: ops.conv3x3_chunked(dy, wb, dx, B=B, H=r_in, W=r_in, cin=cout, ldx=cout, cout=cp, ldy=cp))
         t_pk = timeit(lambda: ops.pack_conv3x3_chunked(w4))
-        line += f" | chunked fwd {t_cf:7.1f} us {gf / t_cf:5.2f} PF, dgrad {t_cd:7.1f} us {gf / t_cd:5.2f} PF, pack {t_pk:5.1f} us"
+        dwn = torch.zeros(cout, 9 * cp, device="cuda")
+        t_cw = timeit(lambda: ops.conv3x3_chunked_wgrad(x, dy, dwn, B=B, H=r_in, W=r_in, cin=cp, cin_pad=cp, ldx=cp, cout=cout, ldy=cout))
+        line += (f" | chunked fwd {t_cf:7.1f} us {gf / t_cf:5.2f} PF, dgrad {t_cd:7.1f} us {gf / t_cd:5.2f} PF, wgrad {t_cw:7.1f} us "
+                 f"{gf / t_cw:5.2f} PF, pack {t_pk:5.1f} us")
     print(line, flush=True)
