@@ -58,6 +58,9 @@ constexpr size_t gemm_lds_bytes() {
 #ifndef MVIT_GEMM_TRANS   // 1: dense tiles accumulate C^T (MFMA operands swapped) and store row-per-lane, no LDS panel
 #define MVIT_GEMM_TRANS 1
 #endif
+#ifndef MVIT_GEMM_MI16    // 1: the 8-wave 256-row tiles run on v_mfma_f32_16x16x32_bf16 (two sub-steps per K tile) instead of 32x32x16
+#define MVIT_GEMM_MI16 1
+#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit_gemm_args p) {
@@ -66,7 +69,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr int RPI = NT / 8;                 // tile rows filled per DMA instruction of the block
   constexpr int NSTAGE = gemm_stages(BM, BN);
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
+  // MFMA shape.  v_mfma_f32_16x16x32_bf16 does the same flops per cycle as 32x32x16 with a quarter of the accumulator traffic per
+  // instruction: on random operands at the socket power cap a bare loop of it sustains 2.03 PFLOP/s against 1.82
+  // (tools/probes/mfma_power.hip), and the dense loops here are power-limited.
+  constexpr bool MI16 = MVIT_GEMM_MI16 && WAVES_M * WAVES_N == 8 && BM == 256 && BN == 128;
+  constexpr int FR = MI16 ? 16 : 32;          // rows of an operand fragment = rows / columns of an accumulator block
+  constexpr int NSUB = MI16 ? 2 : 4;          // MFMA sub-steps per K tile (K = 32 / 16 per instruction)
+  constexpr int CPS = 8 / NSUB;               // 16-byte K chunks per sub-step
+  constexpr int AR = MI16 ? 4 : 16;           // accumulator registers per block
+  constexpr int FSTRIDE = FR * 128;           // LDS bytes between consecutive fragments of a wave's sub-tile
+  using acc_t = std::conditional_t<MI16, f32x4, f32x16>;
+  constexpr int TM = WTM / FR, TN = WTN / FR;
   constexpr int A_CH = BM / RPI, B_CH = BN / RPI;
   constexpr int LPT = A_CH + B_CH;            // DMA instructions per thread per K tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
@@ -82,7 +95,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // transposition through LDS: every lane post-processes and stores pieces of its own row.
   // (Measured and dropped for the epilogues with per-element operands -- residual, SwiGLU, d(SwiGLU): a lane per row means 64
   // different cache lines per load / store instruction, and proj + residual went 39 -> 48 us, dfc2 + d(SwiGLU) 84 -> 100 us.)
-  constexpr bool TRANS = MVIT_GEMM_TRANS && AMODE == MVIT_A_DENSE && EPI == MVIT_EPI_STORE;
+  constexpr bool TRANS = MVIT_GEMM_TRANS && AMODE == MVIT_A_DENSE && EPI == MVIT_EPI_STORE && !MI16;
+  static_assert(!MI16 || (MVIT_GEMM_SEQ && PIPE), "the 16x16x32 K step exists in the explicitly ordered pipeline only");
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
   static_assert((size_t)NW * SLAB * 4 + (size_t)WAVES_M * BN * 8 <= (size_t)BUF_BYTES, "epilogue panel must fit one LDS buffer");
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-  const int frag_row = lane & 31, frag_half = lane >> 5;
+  const int frag_row = lane & (FR - 1), frag_half = lane / FR;   // fragment row and K chunk (inside a sub-step) of this lane
   const int c8 = tid & 7;         // 16-byte slot inside the 64-wide K slice
   const int row_base = tid >> 3;  // 0..RPI-1, +RPI per chunk index
   const int c8s = c8 ^ ((row_base >> 1) & 7);  // source chunk for this lane's LDS slot (same for every +RPI row)
@@ -329,13 +343,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   issue_prologue(cb);
 
   for (;;) {
-    f32x16 acc[TM][TN];
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
+    auto mfma1 = [](const bf16x8& x, const bf16x8& y, const acc_t& c) __attribute__((always_inline)) {
+      if constexpr (MI16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+      else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    };
 
     // ---------------------------------------------------------------- main loop
     int ib = cb + NSTAGE - 1 >= NSTAGE ? cb - 1 : cb + NSTAGE - 1;  // buffer receiving K tile t + NSTAGE - 1
@@ -347,10 +367,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       bf16x8 fa[2][TM], fb[2][TN];
       // fragment addresses: one lane-dependent offset per sub-step and operand; the 32-row fragment stride (4096 B)
       // does not touch the swizzle bits and rides on the ds_read immediate
-      unsigned aoff[4], boff[4];
+      unsigned aoff[NSUB], boff[NSUB];
 #pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) {
-        const unsigned sw = (unsigned)(((s_ * 2 + frag_half) ^ ((frag_row >> 1) & 7)) << 4);
+      for (int s_ = 0; s_ < NSUB; ++s_) {
+        const unsigned sw = (unsigned)(((s_ * CPS + frag_half) ^ ((frag_row >> 1) & 7)) << 4);
         aoff[s_] = (unsigned)(wave_m * WTM + frag_row) * 128u + sw;
         boff[s_] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + frag_row) * 128u + sw;
       }
@@ -365,9 +385,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         const char* pa = a + aoff[s_];
         const char* pb = a + boff[s_];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) xa[i] = *(const bf16x8*)(pa + i * 4096);
+        for (int i = 0; i < TM; ++i) xa[i] = *(const bf16x8*)(pa + i * FSTRIDE);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) xb[j] = *(const bf16x8*)(pb + j * 4096);
+        for (int j = 0; j < TN; ++j) xb[j] = *(const bf16x8*)(pb + j * FSTRIDE);
       };
       auto mma = [&](const bf16x8 (&xa)[TM], const bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
 #if MVIT_ABLATE & 4  // measurement build: operand movement only
@@ -381,8 +401,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[j], xa[i], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i], xb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = TRANS ? mfma1(xb[j], xa[i], acc[i][j]) : mfma1(xa[i], xb[j], acc[i][j]);
       };
       auto wait_tile = [&](int tn) __attribute__((always_inline)) {  // this lane's DMA pieces of K tile tn have landed
         if (NSTAGE == 3 && tn + 1 < t_end)
@@ -439,11 +458,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #if MVIT_ABLATE & 4
           asm volatile("" ::"v"(ca[i]), "v"(cbf[j]));
 #else
-          acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(cbf[j], ca[i], acc[i][j], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], cbf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = TRANS ? mfma1(cbf[j], ca[i], acc[i][j]) : mfma1(ca[i], cbf[j], acc[i][j]);
 #endif
 #pragma unroll
-          for (int c = 0; c < NR + PG; ++c) {
+          for (int c = 0; c < NR + LPT; ++c) {
             if (c < C && c * NMr / C == m - mf0) {
               // DMA pieces evenly between the reads, or (last sub-step before the hand-over) after all of them
               const int before = reads_first ? (c < NR ? 0 : c - NR) : c * ND / C;
@@ -460,9 +478,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
                 if (r == 0)
                   na[0] = *(const bf16x8*)(pa);
                 else if (r <= TN)
-                  nbf[r - 1] = *(const bf16x8*)(pb + (r - 1) * 4096);
+                  nbf[r - 1] = *(const bf16x8*)(pb + (r - 1) * FSTRIDE);
                 else
-                  na[r - TN] = *(const bf16x8*)(pa + (r - TN) * 4096);
+                  na[r - TN] = *(const bf16x8*)(pa + (r - TN) * FSTRIDE);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -487,7 +505,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         constexpr int HO = NM * 3 / 8;
 #endif
         const int rt = t + NSTAGE - 1;  // tile of this step's refill, into buffer ib
-        if constexpr (pre) {
+        if constexpr (MI16) {
+          // two sub-steps of TM x TN MFMAs: the reads of sub-step 1 and the whole refill ride on sub-step 0
+          static_assert(!MI16 || (!pre && !nxt), "no pre-issue on the 16x16x32 step");
+          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, rt, ib, 0, LPT, 0, NM, false, 0);
+        } else if constexpr (pre) {
           sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, rt, ib, Q1, Q2, 0, NM, false, 0);
           sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, rt, ib, Q2, LPT, 0, NM, false, 0);
           sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, rt, ib, 0, 0, 0, NM, false, 0);
@@ -523,14 +545,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         }
         load_frags(a, b, 1, fa[1], fb[1]);
         mma(fa[0], fb[0]);
-        if constexpr (tight)
-          issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, PG>{}, std::integral_constant<int, (2 * PG < LPT ? 2 * PG : LPT)>{});
-        load_frags(a, b, 2, fa[0], fb[0]);
-        mma(fa[1], fb[1]);
-        if constexpr (tight)
-          issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, (2 * PG < LPT ? 2 * PG : LPT)>{}, std::integral_constant<int, LPT>{});
-        load_frags(a, b, 3, fa[1], fb[1]);
-        mma(fa[0], fb[0]);
+        if constexpr (NSUB == 4) {
+          if constexpr (tight)
+            issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, PG>{}, std::integral_constant<int, (2 * PG < LPT ? 2 * PG : LPT)>{});
+          load_frags(a, b, 2, fa[0], fb[0]);
+          mma(fa[1], fb[1]);
+          if constexpr (tight)
+            issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, (2 * PG < LPT ? 2 * PG : LPT)>{}, std::integral_constant<int, LPT>{});
+          load_frags(a, b, 3, fa[1], fb[1]);
+          mma(fa[0], fb[0]);
+        }
         if constexpr (tight) {
 #pragma unroll
           for (int g = 0; g < 3 * (TM + TN); ++g) {
@@ -572,13 +596,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #if MVIT_GEMM_SEQ
         if (t < t_tight) {
           set_piece_offsets(0);
-          if (MVIT_GEMM_PREISSUE && NSTAGE == 2 && t + 1 < t_tight) {  // (three stages have the lead anyway: measured 2 % slower there)
-            kstep_seq(t++, std::false_type{}, std::true_type{});
-            for (; t + 1 < t_tight; ++t) kstep_seq(t, std::true_type{}, std::true_type{});
-            kstep_seq(t++, std::true_type{}, std::false_type{});
-          } else {
-            for (; t < t_tight; ++t) kstep_seq(t, std::false_type{}, std::false_type{});
+          if constexpr (MVIT_GEMM_PREISSUE && NSTAGE == 2) {  // (three stages have the lead anyway: measured 2 % slower there)
+            if (t + 1 < t_tight) {
+              kstep_seq(t++, std::false_type{}, std::true_type{});
+              for (; t + 1 < t_tight; ++t) kstep_seq(t, std::true_type{}, std::true_type{});
+              kstep_seq(t++, std::true_type{}, std::false_type{});
+            }
           }
+          for (; t < t_tight; ++t) kstep_seq(t, std::false_type{}, std::false_type{});
         }
 #else
         for (; t < t_tight; ++t) kstep(t, std::true_type{});
@@ -641,7 +666,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     constexpr int RPP = 64 / CPR;                                      // rows per pass
     constexpr int NPASS = RPP >= 16 ? 1 : 16 / RPP;
     float* stg = (float*)(smem + last * BUF_BYTES) + (size_t)wave * SLAB;
-    const int col_l = lane & 31;
+    const int col_l = lane & (FR - 1);
     const int lr = lane / CPR, lc = (lane % CPR) * V;
     const int colw = en0 + wave_n * WTN;  // first column of this wave's panel
 
@@ -833,21 +858,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          constexpr int NSLAB = TM * 2;
-          const int slab = i * 2 + g;
+        for (int g = 0; g < FR / 16; ++g) {
+          constexpr int NSLAB = WTM / 16;
+          const int slab = i * (FR / 16) + g;
           if (slab + 1 < NSLAB) issue_aux(slab + 1, (slab + 1) & 1);
-          // park rows 32*i + 16*g .. +15 of the wave's sub-tile (accumulator registers 8g .. 8g+7)
+          // park rows FR*i + 16*g .. +15 of the wave's sub-tile: accumulator registers 8g .. 8g+7 of the 32x32 blocks, all four of
+          // the 16x16 blocks (C/D layout there: col = lane & 15, row = 4 * (lane >> 4) + register)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (MI16) {
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8)
-              stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * frag_half) * SLD + j * 32 + col_l] = acc[i][j][8 * g + r8];
+              for (int r4 = 0; r4 < 4; ++r4) stg[(r4 + 4 * frag_half) * SLD + j * 16 + col_l] = acc[i][j][r4];
+            } else {
+#pragma unroll
+              for (int r8 = 0; r8 < 8; ++r8)
+                stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * frag_half) * SLD + j * 32 + col_l] = acc[i][j][8 * g + r8];
+            }
+          }
 #pragma unroll
           for (int it = 0; it < NPASS; ++it) {
             const int rl = it * RPP + lr;  // row inside the slab
             if (RPP > 16 && rl >= 16) continue;
-            const int row = em0 + wave_m * WTM + i * 32 + 16 * g + rl;
+            const int row = em0 + wave_m * WTM + i * FR + 16 * g + rl;
             if constexpr (EPI == MVIT_EPI_SWIGLU) {
               bf16_t* aux = (bf16_t*)p.aux;
               const int ca = col, cbb = col + 32, cg = (colw >> 1) + lc;

@@ -645,10 +645,30 @@ __global__ __launch_bounds__(256, 1) void conv_bwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void conv_bwd_dw3_kernel(const float* __restrict__ part, float* __restrict__ dW3, int NH, int nrows,
                                                            const float* __restrict__ dbpart, int nbrows, float* __restrict__ db3) {
   const int o = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x < NH) {       // db3[h] (row 0 of the caller's [DB3_SLOTS][32] table): block partials in order
+  if (blockIdx.x == gridDim.x - 1) {               // db3[h] (row 0 of the caller's [DB3_SLOTS][32] table): block partials in a fixed order
+    // 16 row segments x 16 heads: every thread sums its segment front to back (independent loads, eight in flight), then the
+    // segment sums are added in segment order -- the same association every run
+    __shared__ double seg[16][MAXH];
+    const int h = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int per = (nbrows + 15) / 16, b0 = sg * per, b1 = min(nbrows, b0 + per);
     double t = 0.;
-    for (int b = 0; b < nbrows; ++b) t += dbpart[(size_t)b * MAXH + threadIdx.x];
-    db3[threadIdx.x] += (float)t;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = dbpart[(size_t)(b + e) * MAXH + h];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t += v[e];
+    }
+    for (; b < b1; ++b) t += dbpart[(size_t)b * MAXH + h];
+    seg[sg][h] = t;
+    __syncthreads();
+    if (threadIdx.x < NH) {
+      double a = 0.;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a += seg[g][threadIdx.x];
+      db3[threadIdx.x] += (float)a;
+    }
   }
   if (o >= NH * 9 * XC) return;
   const int c = o % XC, hd = o / XC, h = hd / 9, d = hd % 9;

@@ -263,6 +263,15 @@ class HipEngine:
         return fz
 
     # ------------------------------------------------------------------ per-step packs of the trainable weights
+    def _fus3_perm(self, cin, dev):
+        """[up | img] channel order of the last fusion block, built once per device: a host tensor moved with .to(dev) inside the
+        step is a pageable copy that waits for the whole stream (the step's prologue would run launch-bound every step)"""
+        key = (cin, str(dev))
+        cache = self.__dict__.setdefault("_perm_cache", {})
+        if key not in cache:
+            cache[key] = torch.cat([torch.arange(3, cin, device=dev), torch.arange(0, 3, device=dev)])
+        return cache[key]
+
     def _pack_trainable(self, need_bwd):
         c = self._config()
         dev = self._require_gpu()
@@ -325,7 +334,7 @@ class HipEngine:
             w = f32(cv.conv.weight).contiguous()                                    # [Cout, Cin, 3, 3]
             cout, cin = w.shape[0], w.shape[1]
             last = i == len(convs) - 1                                              # fus3: internal order [up(64) | img(3)]
-            perm = torch.cat([torch.arange(3, cin), torch.arange(0, 3)]).to(dev) if last else None
+            perm = self._fus3_perm(cin, dev) if last else None
             cp = _pad8(cin)
             chunked = self.use_chunked_conv and 3 <= i < len(convs) - 1 and cin % 8 == 0 and cout % 8 == 0
             if chunked:

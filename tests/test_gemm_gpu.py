@@ -128,7 +128,10 @@ def _pack_swiglu_rows(H):
 
 
 # second case: the 8-wave 256x128 tile of the batch-16 step; third: the 256x256 tile (>= 1024 tiles)
-@pytest.mark.parametrize("M,D,H,Do", [(400, 96, 256, 64), (2100, 200, 384, 136), (8192, 136, 4096, 64)])
+# last two: the backward epilogue at the batch-16 shape, where the product runs as two launches (rows [0, 4096) on 256x256 tiles, the
+# remaining 1168 rows on 256x128 tiles)
+@pytest.mark.parametrize("M,D,H,Do", [(400, 96, 256, 64), (2100, 200, 384, 136), (8192, 136, 4096, 64), (5264, 136, 4096, 64),
+                                      (5264, 200, 4096, 328)])
 def test_gemm_swiglu_fwd_bwd(M, D, H, Do):
     ops = _ops()
     x = _rand(M, D, seed=1).bfloat16()
