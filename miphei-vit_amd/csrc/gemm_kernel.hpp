@@ -58,8 +58,8 @@ constexpr size_t gemm_lds_bytes() {
 #ifndef MVIT_GEMM_TRANS   // 1: dense tiles accumulate C^T (MFMA operands swapped) and store row-per-lane, no LDS panel
 #define MVIT_GEMM_TRANS 1
 #endif
-#ifndef MVIT_GEMM_MI16    // 1: the 8-wave 256-row tiles run on v_mfma_f32_16x16x32_bf16 (two sub-steps per K tile) instead of 32x32x16
-#define MVIT_GEMM_MI16 1
+#ifndef MVIT_GEMM_MI16    // bit 0: the 8-wave 256x128 tile runs on v_mfma_f32_16x16x32_bf16 (two sub-steps per K tile) instead of 32x32x16;
+#define MVIT_GEMM_MI16 1  // measurement builds: bit 1 the 8-wave 256x256 tile too, bit 2 the 4-wave 256-row tiles too
 #endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
@@ -71,8 +71,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   // MFMA shape.  v_mfma_f32_16x16x32_bf16 does the same flops per cycle as 32x32x16 with a quarter of the accumulator traffic per
   // instruction: on random operands at the socket power cap a bare loop of it sustains 2.03 PFLOP/s against 1.82
-  // (tools/probes/mfma_power.hip), and the dense loops here are power-limited.
-  constexpr bool MI16 = MVIT_GEMM_MI16 && WAVES_M * WAVES_N == 8 && BM == 256 && BN == 128;
+  // (tools/probes/mfma_power.hip), and the dense loops here are power-limited.  Measured in the training step,
+  // same box: 8-wave 256x128 tile +3.9 % (the product choice); 8-wave 256x256 tile -0.4 % (fc1 + SwiGLU 153.5 vs 145.2 us; batch-64
+  // inference within noise, embedding extraction -1.6 %); 4-wave 256x128 tile -11 %.
+  constexpr bool MI16 = BM == 256 && (((MVIT_GEMM_MI16 & 1) && WAVES_M * WAVES_N == 8 && BN == 128) ||
+                                      ((MVIT_GEMM_MI16 & 2) && WAVES_M * WAVES_N == 8 && BN == 256) ||
+                                      ((MVIT_GEMM_MI16 & 4) && WAVES_M * WAVES_N == 4));
   constexpr int FR = MI16 ? 16 : 32;          // rows of an operand fragment = rows / columns of an accumulator block
   constexpr int NSUB = MI16 ? 2 : 4;          // MFMA sub-steps per K tile (K = 32 / 16 per instruction)
   constexpr int CPS = 8 / NSUB;               // 16-byte K chunks per sub-step
@@ -80,6 +84,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr int FSTRIDE = FR * 128;           // LDS bytes between consecutive fragments of a wave's sub-tile
   using acc_t = std::conditional_t<MI16, f32x4, f32x16>;
   constexpr int TM = WTM / FR, TN = WTN / FR;
+  // 128-row wave sub-tiles on the 16x16x32 shape: the A fragments of a sub-step are consumed in two groups of TM / 2, so that the
+  // register-double-buffered fragments stay at 2 x (4 + 4) (with all 8 + 4 of a sub-step double-buffered the kernel spills)
+  constexpr int AHALF = (MI16 && TM > 4) ? 2 : 1;
+  constexpr int TMH = TM / AHALF;
   constexpr int A_CH = BM / RPI, B_CH = BN / RPI;
   constexpr int LPT = A_CH + B_CH;            // DMA instructions per thread per K tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
@@ -95,6 +103,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // transposition through LDS: every lane post-processes and stores pieces of its own row.
   // (Measured and dropped for the epilogues with per-element operands -- residual, SwiGLU, d(SwiGLU): a lane per row means 64
   // different cache lines per load / store instruction, and proj + residual went 39 -> 48 us, dfc2 + d(SwiGLU) 84 -> 100 us.)
+  // (Not on the 16x16x32 tiles: a v_permlane16_swap version of the row-per-lane store -- 64-byte row segments per instruction -- was
+  // measured at 81.2 vs 77.6 us for qkv and -0.25 % on the step against the LDS panel.)
   constexpr bool TRANS = MVIT_GEMM_TRANS && AMODE == MVIT_A_DENSE && EPI == MVIT_EPI_STORE && !MI16;
   static_assert(!MI16 || (MVIT_GEMM_SEQ && PIPE), "the 16x16x32 K step exists in the explicitly ordered pipeline only");
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       // fragments are double-buffered in registers - sub-step s+1 is read while the MFMAs of sub-step s run - and
       // the K-tile hand-over (wait for the next tile's DMA, barrier, refill of the buffer just consumed, first
       // fragments of the next tile) sits in front of the LAST sub-step's MFMAs instead of between two K tiles.
-      bf16x8 fa[2][TM], fb[2][TN];
+      bf16x8 fa[2][TMH], fb[2][TN];
       // fragment addresses: one lane-dependent offset per sub-step and operand; the 32-row fragment stride (4096 B)
       // does not touch the swizzle bits and rides on the ds_read immediate
       unsigned aoff[NSUB], boff[NSUB];
@@ -374,10 +384,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         aoff[s_] = (unsigned)(wave_m * WTM + frag_row) * 128u + sw;
         boff[s_] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + frag_row) * 128u + sw;
       }
-      auto load_frags = [&](const char* a, const char*, int s_, bf16x8 (&xa)[TM], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+      auto load_frags = [&](const char* a, const char*, int s_, bf16x8 (&xa)[TMH], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
 #if MVIT_ABLATE & 2  // measurement build: fragments stay whatever the first read left in the registers
 #pragma unroll
-        for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(xa[i]));
+        for (int i = 0; i < TMH; ++i) asm volatile("" : "=v"(xa[i]));
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" : "=v"(xb[j]));
         return;
@@ -385,23 +395,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         const char* pa = a + aoff[s_];
         const char* pb = a + boff[s_];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) xa[i] = *(const bf16x8*)(pa + i * FSTRIDE);
+        for (int i = 0; i < TMH; ++i) xa[i] = *(const bf16x8*)(pa + i * FSTRIDE);
 #pragma unroll
         for (int j = 0; j < TN; ++j) xb[j] = *(const bf16x8*)(pb + j * FSTRIDE);
       };
-      auto mma = [&](const bf16x8 (&xa)[TM], const bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+      // (AHALF == 2) the A fragments of group h of sub-step s_, alone
+      auto load_a_half = [&](const char* a, int s_, int h, bf16x8 (&xa)[TMH]) __attribute__((always_inline)) {
+        const char* pa = a + aoff[s_] + h * TMH * FSTRIDE;
+#pragma unroll
+        for (int i = 0; i < TMH; ++i) xa[i] = *(const bf16x8*)(pa + i * FSTRIDE);
+      };
+      auto mma = [&](const bf16x8 (&xa)[TMH], const bf16x8 (&xb)[TN], int h = 0) __attribute__((always_inline)) {
 #if MVIT_ABLATE & 4  // measurement build: operand movement only
 #pragma unroll
-        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xa[i]));
+        for (int i = 0; i < TMH; ++i) asm volatile("" ::"v"(xa[i]));
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(xb[j]));
         return;
 #endif
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TMH; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = TRANS ? mfma1(xb[j], xa[i], acc[i][j]) : mfma1(xa[i], xb[j], acc[i][j]);
+            acc[h * TMH + i][j] = TRANS ? mfma1(xb[j], xa[i], acc[h * TMH + i][j]) : mfma1(xa[i], xb[j], acc[h * TMH + i][j]);
       };
       auto wait_tile = [&](int tn) __attribute__((always_inline)) {  // this lane's DMA pieces of K tile tn have landed
         if (NSTAGE == 3 && tn + 1 < t_end)
@@ -444,24 +460,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(a + A_BYTES + (j - A_CH) * RPI * 128), 16, off, soff, 0, 0);
         }
       };
-      auto sub_seq = [&](const bf16x8 (&ca)[TM], const bf16x8 (&cbf)[TN], bf16x8 (&na)[TM], bf16x8 (&nbf)[TN],
-                         const char* rbase, int rs, int dt, int dbuf, int p0, int p1, int mf0, int mf1, bool reads_first, auto tag) __attribute__((always_inline)) {
+      auto sub_seq = [&](const bf16x8 (&ca)[TMH], const bf16x8 (&cbf)[TN], bf16x8 (&na)[TMH], bf16x8 (&nbf)[TN],
+                         const char* rbase, int rs, int dt, int dbuf, int p0, int p1, int mf0, int mf1, bool reads_first, auto tag,
+                         int ch = 0, int rh = 0, bool rb = true) __attribute__((always_inline)) {
         // dt / dbuf: K tile and LDS buffer of the DMA pieces [p0, p1)
         // MFMAs [mf0, mf1) of the sub-step; the companions (all NR reads when mf1 is the end, DMA pieces [p0, p1)) are spread over them
-        constexpr int NR = TM + TN, NM = TM * TN;
+        // (AHALF == 2) ch: A group the MFMAs work on; rh: A group of sub-step rs that is read; rb: whether the B fragments are read too
+        const int NR = TMH + (rb ? TN : 0);
+        constexpr int NM = TMH * TN;
         const int ND = p1 - p0, C = (mf1 == NM ? NR : 0) + ND, NMr = mf1 - mf0;
-        const char* pa = rbase + aoff[rs];
+        const char* pa = rbase + aoff[rs] + rh * TMH * FSTRIDE;
         const char* pb = rbase + boff[rs];
 #pragma unroll
         for (int m = mf0; m < mf1; ++m) {
-          const int i = m / TN, j = m % TN;
+          const int i = m / TN, j = m % TN, ia = ch * TMH + i;
 #if MVIT_ABLATE & 4
           asm volatile("" ::"v"(ca[i]), "v"(cbf[j]));
 #else
-          acc[i][j] = TRANS ? mfma1(cbf[j], ca[i], acc[i][j]) : mfma1(ca[i], cbf[j], acc[i][j]);
+          acc[ia][j] = TRANS ? mfma1(cbf[j], ca[i], acc[ia][j]) : mfma1(ca[i], cbf[j], acc[ia][j]);
 #endif
 #pragma unroll
-          for (int c = 0; c < NR + LPT; ++c) {
+          for (int c = 0; c < TMH + TN + LPT; ++c) {
             if (c < C && c * NMr / C == m - mf0) {
               // DMA pieces evenly between the reads, or (last sub-step before the hand-over) after all of them
               const int before = reads_first ? (c < NR ? 0 : c - NR) : c * ND / C;
@@ -477,6 +496,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #endif
                 if (r == 0)
                   na[0] = *(const bf16x8*)(pa);
+                else if (!rb)
+                  na[r] = *(const bf16x8*)(pa + r * FSTRIDE);
                 else if (r <= TN)
                   nbf[r - 1] = *(const bf16x8*)(pb + (r - 1) * FSTRIDE);
                 else
@@ -496,7 +517,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         constexpr bool pre = decltype(pre_tag)::value, nxt = decltype(nxt_tag)::value;
         const char* a = smem + cb * BUF_BYTES;
         constexpr int Q1 = PG < LPT ? PG : LPT, Q2 = 2 * PG < LPT ? 2 * PG : LPT;
-        constexpr int NM = TM * TN;
+        constexpr int NM = TMH * TN;
         // MFMAs of the last sub-step issued before the hand-over, so that its fragment reads have landed at the barrier and the
         // next tile's first fragments still get some MFMAs of lead (measured: 1 of 4 and 3 of 8 are the best splits)
 #ifdef MVIT_GEMM_HO
@@ -505,10 +526,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         constexpr int HO = NM * 3 / 8;
 #endif
         const int rt = t + NSTAGE - 1;  // tile of this step's refill, into buffer ib
-        if constexpr (MI16) {
+        if constexpr (MI16 && AHALF == 2) {
+          // two sub-steps x two A groups = four phases of TMH x TN MFMAs; the B fragments change with the sub-step only:
+          //   phase 0 (s0, g0): read A(s0, g1)            phase 1 (s0, g1): read A(s1, g0) and B(s1)
+          //   phase 2 (s1, g0): read A(s1, g1)            phase 3 (s1, g1): hand-over, read A(s0, g0) and B(s0) of the next tile
+          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 0, rt, ib, pre ? Q1 : 0, pre ? Q2 : Q1, 0, NM, false, 0, 0, 1, false);
+          sub_seq(fa[1], fb[0], fa[0], fb[1], a, 1, rt, ib, pre ? Q2 : Q1, pre ? LPT : Q2, 0, NM, false, 0, 1, 0, true);
+          sub_seq(fa[0], fb[1], fa[1], fb[0], a, 1, rt, ib, pre ? 0 : Q2, pre ? 0 : LPT, 0, NM, !pre, 0, 0, 1, false);
+        } else if constexpr (MI16) {
           // two sub-steps of TM x TN MFMAs: the reads of sub-step 1 and the whole refill ride on sub-step 0
-          static_assert(!MI16 || (!pre && !nxt), "no pre-issue on the 16x16x32 step");
-          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, rt, ib, 0, LPT, 0, NM, false, 0);
+          sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, rt, ib, pre ? Q1 : 0, LPT, 0, NM, false, 0);
         } else if constexpr (pre) {
           sub_seq(fa[0], fb[0], fa[1], fb[1], a, 1, rt, ib, Q1, Q2, 0, NM, false, 0);
           sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, rt, ib, Q2, LPT, 0, NM, false, 0);
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           sub_seq(fa[1], fb[1], fa[0], fb[0], a, 2, rt, ib, Q1, Q2, 0, NM, false, 0);
           sub_seq(fa[0], fb[0], fa[1], fb[1], a, 3, rt, ib, Q2, LPT, 0, NM, true, 0);
         }
-        if (HO > 0) sub_seq(fa[1], fb[1], fa[0], fb[0], a, 0, rt, ib, 0, 0, 0, HO, false, 0);
+        if (HO > 0) sub_seq(fa[1], fb[1], fa[0], fb[0], a, 0, rt, ib, 0, 0, 0, HO, false, 0, AHALF - 1);
         const int nb = cb + 1 == NSTAGE ? 0 : cb + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (NSTAGE == 3)
@@ -529,7 +556,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         __builtin_amdgcn_sched_barrier(0);
         // behind the hand-over: first fragments of the next tile, then (nxt) the first pieces of tile t + NSTAGE into the buffer
         // every wave has just finished reading (the one this step consumed)
-        sub_seq(fa[1], fb[1], fa[0], fb[0], smem + nb * BUF_BYTES, 0, t + NSTAGE, cb, 0, nxt ? Q1 : 0, HO, NM, true, 0);
+        sub_seq(fa[1], fb[1], fa[0], fb[0], smem + nb * BUF_BYTES, 0, t + NSTAGE, cb, 0, nxt ? Q1 : 0, HO, NM, true, 0, AHALF - 1, 0, true);
         cb = nb;
         ib = ib + 1 == NSTAGE ? 0 : ib + 1;
       };
@@ -543,8 +570,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         } else {
           if (t + NSTAGE - 1 < t_end) issue_tile(t + NSTAGE - 1, ib);
         }
+        if constexpr (AHALF == 2) {   // four phases, as in kstep_seq
+          load_a_half(a, 0, 1, fa[1]);
+          mma(fa[0], fb[0], 0);
+          load_frags(a, b, 1, fa[0], fb[1]);
+          mma(fa[1], fb[0], 1);
+          load_a_half(a, 1, 1, fa[1]);
+          mma(fa[0], fb[1], 0);
+        } else {
         load_frags(a, b, 1, fa[1], fb[1]);
         mma(fa[0], fb[0]);
+        }
         if constexpr (NSUB == 4) {
           if constexpr (tight)
             issue_pieces_fast(t + NSTAGE - 1, ib, std::integral_constant<int, PG>{}, std::integral_constant<int, (2 * PG < LPT ? 2 * PG : LPT)>{});
@@ -578,7 +614,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           __builtin_amdgcn_s_barrier();
           load_frags(smem + nb * BUF_BYTES, smem + nb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
         }
-        mma(fa[1], fb[1]);
+        mma(fa[1], fb[1], AHALF - 1);
         if constexpr (tight) {
 #pragma unroll
           for (int g = 0; g < TM + TN; ++g) {
