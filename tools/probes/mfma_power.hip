@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
     while (dt < 3.0) { launch(); hipDeviceSynchronize(); ++n; dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
     // per wave and iteration: 16 x 32x32x16 (32768 flop each) for kernel 0, 64 x 16x16x32 (16384 flop each) for the others.
     // (Round 1-2 credited every kernel with 16 x 32768: the 16x16x32 loops were under-reported by 2x -- the 'half the rate' puzzle of
-    // DESIGN.md section 6b was this line, not the instruction.)
+    // DESIGN.md section 6c was this line, not the instruction.)
     const double flops = (double)n * grid * 4 /*waves*/ * iters * (which == 0 ? 16 * 32768.0 : 64 * 16384.0);
     printf("%s %s, %d wave(s)/SIMD: %.1f TF/s sustained over %.1f s\n", which == 0 ? "v_mfma_f32_32x32x16_bf16" : which == 1 ? "v_mfma_f32_16x16x32_bf16 (A held)" : which == 2 ? "v_mfma_f32_16x16x32_bf16 (B held, s_nop between)" : "v_mfma_f32_16x16x32_bf16 (16 accumulators)",
            zeros ? "zeros" : "random", wps, flops / dt / 1e12, dt);
