@@ -58,6 +58,9 @@ constexpr size_t gemm_lds_bytes() {
 #ifndef MVIT_GEMM_TRANS   // 1: dense tiles accumulate C^T (MFMA operands swapped) and store row-per-lane, no LDS panel
 #define MVIT_GEMM_TRANS 1
 #endif
+#ifndef MVIT_GEMM_LATE_CONST   // 1: measurement build, epilogue column constants fetched at the head of the epilogue (the former order)
+#define MVIT_GEMM_LATE_CONST 0
+#endif
 #ifndef MVIT_GEMM_MI16    // bit 0: the 8-wave 256x128 tile runs on v_mfma_f32_16x16x32_bf16 (two sub-steps per K tile) instead of 32x32x16;
 #define MVIT_GEMM_MI16 1  // measurement builds: bit 1 the 8-wave 256x256 tile too, bit 2 the 4-wave 256-row tiles too
 #endif
@@ -360,6 +363,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
+    // Column constants of this tile's epilogue (bias, LayerScale), requested BEFORE the main loop where the registers allow it
+    // (EARLY_CONST): fetched at the head of the epilogue they sit behind the next tile's prologue DMA in the VM queue, and the
+    // `s_waitcnt vmcnt(0)` in front of their first use made every epilogue wait for that prologue to land (loads return in order).
+    constexpr int V = 8;
+    constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 32 / V : WTN / V;  // lanes per output row
+    constexpr bool EARLY_CONST = !MVIT_GEMM_LATE_CONST && PIPE && BM * BN <= 256 * 128 && !TRANS;
+    const int lc = (lane % CPR) * V;
+    float bias[V], gam[V], bias2[V];
+    auto load_col_consts = [&](int tile_n0) __attribute__((always_inline)) {
+      const int col_ = tile_n0 + wave_n * WTN + lc;
+      const int nv_ = (EPI == MVIT_EPI_SWIGLU) ? V : min(V, p.N - col_);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        if constexpr (EPI == MVIT_EPI_SWIGLU) {
+          bias[e] = p.bias ? p.bias[col_ + e] : 0.f;
+          bias2[e] = p.bias ? p.bias[col_ + 32 + e] : 0.f;
+          gam[e] = 1.f;
+        } else {
+          bias[e] = (p.bias && e < nv_) ? p.bias[col_ + e] : 0.f;
+          gam[e] = (p.gamma && e < nv_) ? p.gamma[col_ + e] : 1.f;
+          bias2[e] = 0.f;
+        }
+      }
+    };
+    if constexpr (EARLY_CONST) load_col_consts(n0);
     auto mfma1 = [](const bf16x8& x, const bf16x8& y, const acc_t& c) __attribute__((always_inline)) {
       if constexpr (MI16)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
@@ -697,13 +725,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  16-row slabs of the wave's
     // sub-tile are parked in a wave-private f32 panel and re-read row-wise: each lane applies the epilogue to 8
     // consecutive columns of one row and issues 16-byte stores; CPR lanes cover one contiguous row segment.
-    constexpr int V = 8;
-    constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 32 / V : WTN / V;  // lanes per output row
     constexpr int RPP = 64 / CPR;                                      // rows per pass
     constexpr int NPASS = RPP >= 16 ? 1 : 16 / RPP;
     float* stg = (float*)(smem + last * BUF_BYTES) + (size_t)wave * SLAB;
     const int col_l = lane & (FR - 1);
-    const int lr = lane / CPR, lc = (lane % CPR) * V;
+    const int lr = lane / CPR;
     const int colw = en0 + wave_n * WTN;  // first column of this wave's panel
 
     auto ld8bf = [&](const bf16_t* q, float (&o)[V], int nv) __attribute__((always_inline)) {
@@ -755,19 +781,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     // column-dependent epilogue constants
     const int col = colw + lc;
     const int nv = (EPI == MVIT_EPI_SWIGLU) ? V : min(V, p.N - col);  // valid columns of this lane's group
-    float bias[V], gam[V], bias2[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      if constexpr (EPI == MVIT_EPI_SWIGLU) {
-        bias[e] = p.bias ? p.bias[col + e] : 0.f;
-        bias2[e] = p.bias ? p.bias[col + 32 + e] : 0.f;
-        gam[e] = 1.f;
-      } else {
-        bias[e] = (p.bias && e < nv) ? p.bias[col + e] : 0.f;
-        gam[e] = (p.gamma && e < nv) ? p.gamma[col + e] : 1.f;
-        bias2[e] = 0.f;
-      }
-    }
+    if constexpr (!EARLY_CONST) load_col_consts(en0);
 
     // Epilogues that READ per-element operands (residual stream, saved SwiGLU pre-activation) fetch them one slab
     // ahead: otherwise every row pass would expose a full HBM round trip behind its dependent store.

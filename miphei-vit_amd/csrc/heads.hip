@@ -124,21 +124,25 @@ __device__ __forceinline__ void load_w1s(const float* __restrict__ W1, const flo
                                          const float* __restrict__ shift, int nch, int lane, bool write_lo,
                                          bf16x8 (&w)[NBLK][2], bf16x8 (*wlo)[64], float (&bias)[NBLK]) {
   const int l31 = lane & 31, half = lane >> 5;
+  // Every load below is UNCONDITIONAL on a clamped channel and masked by a multiplication: with `ok ? W1[..] : 0` hipcc branches
+  // around each load and waits for it (152 dependent L2 round trips per block in the gate kernel: most of its 95 us).
 #pragma unroll
   for (int blk = 0; blk < NBLK; ++blk) {
     const int ch = blk * 32 + l31;
     const bool ok = ch < nch;
-    const float sc = ok ? scale[ch] : 0.f;
+    const int chc = ok ? ch : nch - 1;
+    const float okf = ok ? 1.f : 0.f;
+    const float sc = scale[chc] * okf;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       float f[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = ok ? W1[(size_t)ch * XC + ks * 16 + half * 8 + e] * sc : 0.f;
+      for (int e = 0; e < 8; ++e) f[e] = W1[(size_t)chc * XC + ks * 16 + half * 8 + e] * sc;
       bf16x8 lo;
       frag8_split(f, w[blk][ks], lo);
       if (write_lo) wlo[2 * blk + ks][lane] = lo;
     }
-    bias[blk] = ok ? b1[ch] * sc + shift[ch] : 0.f;
+    bias[blk] = (b1[chc] * sc + shift[chc]) * okf;
   }
 }
 
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = (f >> 1) * 32 + acc_row(8 * (f & 1) + e, half);
-      v[e] = (l31 == f && c < nch) ? W2[c] : 0.f;
+      v[e] = W2[c < nch ? c : nch - 1] * ((l31 == f && c < nch) ? 1.f : 0.f);   // (unconditional load, see load_w1s)
     }
     w2s[f][lane] = frag8(v);
   }
@@ -292,9 +296,12 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const bf16_t* __restri
   const bf16x8 ones = frag_lo(half == 0 ? 0x3f803f80u : 0u);
   float b2r[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) b2r[j] = acc_row(j, half) < NH ? b2[acc_row(j, half)] : 0.f;
+  for (int j = 0; j < 8; ++j) b2r[j] = b2[min(acc_row(j, half), NH - 1)] * (acc_row(j, half) < NH ? 1.f : 0.f);
 
   const long long ntile = (M + 31) / 32;
+  // (Measured on this loop and dropped: the four chains of a group of channel blocks issued round-robin with two psi accumulators --
+  // 256 registers, 78 vs 72 us; the next tile's pixel rows requested one iteration ahead -- 73.8 vs 71.9 us.  A wave's tile is a
+  // dependent chain of 56 MFMAs and 320 VALU operations, and at two waves per SIMD the kernel runs at that chain's latency.)
   for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
     const long long p = t * 32 + l31;
     const bool live = p < M;
@@ -719,15 +726,17 @@ __global__ __launch_bounds__(512, 1) void gate_bwd_reduce_kernel(const bf16_t* _
   for (int b = 0; b < WB; ++b) {
     const int ch = (cg * WB + b) * 32 + l31;
     const bool ok = ch < nch;
-    const float sc = ok ? scale[ch] : 0.f;
+    const int chc = ok ? ch : nch - 1;            // (unconditional loads on a clamped channel, see load_w1s)
+    const float okf = ok ? 1.f : 0.f;
+    const float sc = scale[chc] * okf;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       float f[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = ok ? W1[(size_t)ch * XC + ks * 16 + half * 8 + e] * sc : 0.f;
+      for (int e = 0; e < 8; ++e) f[e] = W1[(size_t)chc * XC + ks * 16 + half * 8 + e] * sc;
       frag8_split(f, wB[b][ks], wBl[b][ks]);
     }
-    thr[b] = ok ? -(b1[ch] * sc + shift[ch]) : 0.f;  // a > 0  <=>  W1s x > -bias
+    thr[b] = -(b1[chc] * sc + shift[chc]) * okf;  // a > 0  <=>  W1s x > -bias
   }
   f32x16 Z[WB];
   float sr[WB], dbh[8];
@@ -936,7 +945,8 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_apply_kernel(const bf16_t* __
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = (f >> 1) * 32 + acc_row(8 * (f & 1) + e, half);
-      v[e] = c < nch ? coef[4 * c] * W1[(size_t)c * XC + l31] : 0.f;
+      const int cc = c < nch ? c : nch - 1;
+      v[e] = coef[4 * cc] * W1[(size_t)cc * XC + l31] * (c < nch ? 1.f : 0.f);
     }
     wK[f][lane] = frag8(v);
   }

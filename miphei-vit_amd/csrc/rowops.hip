@@ -7,21 +7,29 @@
 namespace {
 
 constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+}  // namespace
+constexpr int LN_MAXV_GENERIC = 8;
+namespace {
 
 // ------------------------------------------------------------------ LayerNorm forward
+// NVF > 0: the row is exactly NVF full groups of 64 float4 (D = 256 * NVF: 1536 = 6): no per-group bounds test.  With the test
+// (`if (idx < nv) v[i] = xr[idx]` in an unrolled loop) hipcc branches around every load and waits for it before the next one:
+// a wave paid one HBM round trip PER GROUP (9 `s_waitcnt vmcnt(0)` for 10 loads in this kernel, 13 in the backward one).
+template <int NVF>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, bf16_t* __restrict__ out, int M, int D,
                                                      float eps) {
+  constexpr int LN_MAXV = NVF ? NVF : ::LN_MAXV_GENERIC;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const int nv = D >> 2;
+  const int nv = NVF ? 64 * NVF : D >> 2;
   const float4* xr = (const float4*)(x + (size_t)row * D);
   float4 v[LN_MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
+    if (NVF || idx < nv) {
       v[i] = xr[idx];
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -31,23 +39,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
+    if (NVF || idx < nv) {
       const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
       q += (a * a + bb * bb) + (c * c + d * d);
     }
   }
   const float rs = rsqrtf(wave_sum(q) / D + eps);
   uint2* o = (uint2*)(out + (size_t)row * D);
+  // all results first, then all stores: a load issued behind a store waits for that store too (vmcnt counts both)
+  uint2 r[LN_MAXV];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
+    if (NVF || idx < nv) {
       const float4 ww = ((const float4*)w)[idx], bv = ((const float4*)b)[idx];
-      uint2 r;
-      r.x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
-      r.y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
-      o[idx] = r;
+      r[i].x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
+      r[i].y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
     }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + 64 * i;
+    if (NVF || idx < nv) o[idx] = r[i];
   }
 }
 
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #define MVIT_LNL_ROWS 16
 #endif
 constexpr int LNL_ROWS = MVIT_LNL_ROWS;   // rows (= waves) per block: 16, or 8 with the upper half of the MFMA rows idle
-template <int NV>  // float4 groups per lane: D <= 256 * NV
+template <int NV, bool FULL = false>  // float4 groups per lane: D <= 256 * NV (FULL: D == 256 * NV, no bounds tests, see ln_fwd_kernel)
 __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                     const float* __restrict__ b, bf16_t* __restrict__ out,
                                                                     const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t,
@@ -82,24 +95,27 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
     const float4* xr = (const float4*)(x + (size_t)(row < M ? row : M - 1) * D) + lane;   // + 64 * i: immediate offsets
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < nv) v[i] = xr[64 * i];
+      if (FULL || lane + 64 * i < nv) v[i] = xr[64 * i];
   }
   {
     const int h16 = D >> 3;                           // 16-byte pieces per adapter row (D % 8 == 0 is checked by the host)
     for (int i = threadIdx.x; i < 16 * h16; i += 64 * LNL_ROWS) {
       const int j = i / h16, c = i - j * h16;
-      *(uint4*)(As + j * RS + c * 16) = j < R2 ? ((const uint4*)AcatT)[(size_t)j * h16 + c] : make_uint4(0, 0, 0, 0);
+      uint4 tq = ((const uint4*)AcatT)[(size_t)(j < R2 ? j : R2 - 1) * h16 + c];   // unconditional load (see ln_fwd_kernel), masked
+      const unsigned keep = j < R2 ? 0xffffffffu : 0u;
+      tq.x &= keep, tq.y &= keep, tq.z &= keep, tq.w &= keep;
+      *(uint4*)(As + j * RS + c * 16) = tq;
     }
   }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    if (FULL || lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   const float mu = wave_sum(s) / D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (lane + 64 * i < nv) {
+    if (FULL || lane + 64 * i < nv) {
       const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
       q += (a * a + bb * bb) + (c * c + d * d);
     }
@@ -109,16 +125,20 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
     uint2* hl = (uint2*)(Hs + wave * RS) + lane;
     const float4* wl = (const float4*)w + lane;
     const float4* bl = (const float4*)b + lane;
+    uint2 r[NV];     // all results first, then all stores (see ln_fwd_kernel)
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < nv) {
+      if (FULL || lane + 64 * i < nv) {
         const float4 ww = wl[64 * i], bv = bl[64 * i];
-        uint2 r;
-        r.x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
-        r.y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
-        if (row < M) o[64 * i] = r;
-        hl[64 * i] = r;
+        r[i].x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
+        r[i].y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
+        hl[64 * i] = r[i];
       }
+    if (row < M) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (FULL || lane + 64 * i < nv) o[64 * i] = r[i];
+    }
   }
   __syncthreads();
   // t block [16 tokens][16 columns]: K steps of 32, step ks handled by wave ks % 4.  Every wave of the block stays alive through
@@ -158,7 +178,8 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
 // (A leaner variant -- gradient row kept packed, running gradient fetched after the reductions, 80 registers = 6 waves per SIMD so
 // that all 5264 rows of the training shape are resident in one round -- measured 23.3 us like this one in isolation and 0.5 % slower
 // inside the step, 433.4 vs 435.8 tiles/s same box: the late loads of the running gradient are exposed there.)
-template <int NV>  // float4 groups per lane (D <= 256 * NV): the three row images below are 12 * NV registers
+template <int NV, bool FULL = false>  // float4 groups per lane (D <= 256 * NV; FULL: D == 256 * NV, no bounds tests -- see
+                                       // ln_fwd_kernel); the three row images below are 12 * NV registers
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dh, const float* __restrict__ x,
                                                      const float* __restrict__ w, float* __restrict__ dx,
                                                      const float* __restrict__ gamma_next, bf16_t* __restrict__ dy,
@@ -167,27 +188,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float rsn = rowscale_next ? rowscale_next[row] : 1.f;   // DropPath factor of the branch dy feeds (per sample)
-  const int nv = D >> 2;
+  const int nv = FULL ? 64 * NV : D >> 2;
   const float4* xr = (const float4*)(x + (size_t)row * D);
   const uint2* gr = (const uint2*)(dh + (size_t)row * D);
   float4 v[NV], g[NV], o[NV];
   float4* dxr = (float4*)(dx + (size_t)row * D);
   float s = 0.f;
+  // every operand of the row is requested before anything is used (the running gradient too: read after the reductions it would
+  // sit behind each store of the last loop -- same array -- one exposed HBM latency per element group)
+  uint2 gp[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
+    if (FULL || idx < nv) {
       v[i] = xr[idx];
-      // the running gradient is fetched with the other operands: read after the reductions it would sit behind each store
-      // of the loop below (same array), one exposed HBM latency per element group
-      o[i] = accumulate ? dxr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      gp[i] = gr[idx];
+      g[i] = ((const float4*)w)[idx];
+      if (accumulate) o[i] = dxr[idx];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (FULL || idx < nv) {
+      if (!accumulate) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      const uint2 t = gr[idx];
-      const float4 ww = ((const float4*)w)[idx];
-      g[i].x = __uint_as_float(t.x << 16) * ww.x;
-      g[i].y = __uint_as_float(t.x & 0xffff0000u) * ww.y;
-      g[i].z = __uint_as_float(t.y << 16) * ww.z;
-      g[i].w = __uint_as_float(t.y & 0xffff0000u) * ww.w;
+      g[i].x *= __uint_as_float(gp[i].x << 16);
+      g[i].y *= __uint_as_float(gp[i].x & 0xffff0000u);
+      g[i].z *= __uint_as_float(gp[i].y << 16);
+      g[i].w *= __uint_as_float(gp[i].y & 0xffff0000u);
     }
   }
   const float mu = wave_sum(s) / D;
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
+    if (FULL || idx < nv) {
       v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
       q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
+    if (FULL || idx < nv) {
       v[i].x *= rs; v[i].y *= rs; v[i].z *= rs; v[i].w *= rs;  // xhat
       c1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
       c2 += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
@@ -214,22 +243,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   c1 = wave_sum(c1) / D;
   c2 = wave_sum(c2) / D;
   uint2* dyr = dy ? (uint2*)(dy + (size_t)row * D) : nullptr;
+  // the results replace the running-gradient image, the LayerScale vector of the next product is fetched for the whole row, and
+  // only then do the stores start: a load between two stores waits for the store in front of it (vmcnt counts both)
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
-      float4 r;
-      r.x = rs * (g[i].x - c1 - v[i].x * c2);
-      r.y = rs * (g[i].y - c1 - v[i].y * c2);
-      r.z = rs * (g[i].z - c1 - v[i].z * c2);
-      r.w = rs * (g[i].w - c1 - v[i].w * c2);
-      r.x += o[i].x; r.y += o[i].y; r.z += o[i].z; r.w += o[i].w;
-      dxr[idx] = r;
+    if (FULL || idx < nv) {
+      o[i].x += rs * (g[i].x - c1 - v[i].x * c2);
+      o[i].y += rs * (g[i].y - c1 - v[i].y * c2);
+      o[i].z += rs * (g[i].z - c1 - v[i].z * c2);
+      o[i].w += rs * (g[i].w - c1 - v[i].w * c2);
+      if (dyr) g[i] = ((const float4*)gamma_next)[idx];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (FULL || idx < nv) {
+      dxr[idx] = o[i];
       if (dyr) {
-        const float4 gm = ((const float4*)gamma_next)[idx];
         uint2 p;
-        p.x = pack2bf(r.x * gm.x * rsn, r.y * gm.y * rsn);
-        p.y = pack2bf(r.z * gm.z * rsn, r.w * gm.w * rsn);
+        p.x = pack2bf(o[i].x * g[i].x * rsn, o[i].y * g[i].y * rsn);
+        p.y = pack2bf(o[i].z * g[i].z * rsn, o[i].w * g[i].w * rsn);
         dyr[idx] = p;
       }
     }
@@ -347,7 +382,14 @@ MVIT_API int mvit_layernorm_fwd(const float* x, const float* w, const float* b, 
                                 mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 3) || D > 256 * LN_MAXV) return MVIT_EINVAL;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)out, M, D, eps);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)out, M, D, eps);
+  };
+  if (D == 1536) launch(ln_fwd_kernel<6>);
+  else if (D == 1024) launch(ln_fwd_kernel<4>);
+  else if (D == 2048) launch(ln_fwd_kernel<8>);
+  else if (D == 512) launch(ln_fwd_kernel<2>);
+  else launch(ln_fwd_kernel<0>);
   return MVIT_LAUNCH_CHECK();
 }
 
@@ -362,7 +404,11 @@ MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float
                        (bf16_t*)out, (const bf16_t*)AcatT, (bf16_t*)t, M, D, eps, R2);
     return MVIT_LAUNCH_CHECK();
   };
-  static mvit_per_device_size r2, r4, r6, r8;
+  static mvit_per_device_size r2, r4, r6, r8, f2, f4, f6, f8;
+  if (D == 1536) return launch(ln_fwd_lora_kernel<6, true>, f6);
+  if (D == 1024) return launch(ln_fwd_lora_kernel<4, true>, f4);
+  if (D == 2048) return launch(ln_fwd_lora_kernel<8, true>, f8);
+  if (D == 512) return launch(ln_fwd_lora_kernel<2, true>, f2);
   if (D <= 512) return launch(ln_fwd_lora_kernel<2>, r2);
   if (D <= 1024) return launch(ln_fwd_lora_kernel<4>, r4);
   if (D <= 1536) return launch(ln_fwd_lora_kernel<6>, r6);
@@ -380,6 +426,10 @@ MVIT_API int mvit_layernorm_bwd(const void* dh, const float* x, const float* w, 
                        (bf16_t*)dy, M, D, eps, accumulate, rowscale_next);
     return MVIT_LAUNCH_CHECK();
   };
+  if (D == 1536) return launch(ln_bwd_kernel<6, true>);
+  if (D == 1024) return launch(ln_bwd_kernel<4, true>);
+  if (D == 2048) return launch(ln_bwd_kernel<8, true>);
+  if (D == 512) return launch(ln_bwd_kernel<2, true>);
   if (D <= 512) return launch(ln_bwd_kernel<2>);
   if (D <= 1024) return launch(ln_bwd_kernel<4>);
   if (D <= 1536) return launch(ln_bwd_kernel<6>);

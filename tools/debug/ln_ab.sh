@@ -1,6 +1,6 @@
-timeout 600 python3 -m pytest tests/test_rowops_gpu.py -x -q 2>&1 | tail -2
-echo "occ6"; python3 tools/bench_small.py 2>/dev/null | grep "ln_"
-echo "occ5"; MIPHEI_DBG_LIB=1 python3 tools/bench_small.py 2>/dev/null | grep "ln_"
+timeout 600 python3 -m pytest tests/test_rowops_gpu.py tests/test_heads_gpu.py tests/test_gemm_gpu.py -x -q 2>&1 | tail -2
+echo "product"; python3 tools/bench_small.py 2>/dev/null | grep "ln_"; python3 tools/bench_epi.py 2>/dev/null
+echo "dbg"; MIPHEI_DBG_LIB=1 python3 tools/bench_small.py 2>/dev/null | grep "ln_"; MIPHEI_DBG_LIB=1 python3 tools/bench_epi.py 2>/dev/null
 for r in 1 2; do
 echo "product"; python3 bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | cut -c1-140
 echo "dbg"; python3 tools/bench_dbg.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | cut -c1-140
