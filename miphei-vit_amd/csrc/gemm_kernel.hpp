@@ -61,6 +61,9 @@ constexpr size_t gemm_lds_bytes() {
 #ifndef MVIT_GEMM_LATE_CONST   // 1: measurement build, epilogue column constants fetched at the head of the epilogue (the former order)
 #define MVIT_GEMM_LATE_CONST 0
 #endif
+#ifndef MVIT_GEMM_LATE_PROLOGUE   // 1: measurement build, the next tile's prologue DMA issued behind the first epilogue slab
+#define MVIT_GEMM_LATE_PROLOGUE 0
+#endif
 #ifndef MVIT_GEMM_MI16    // bit 0: the 8-wave 256x128 tile runs on v_mfma_f32_16x16x32_bf16 (two sub-steps per K tile) instead of 32x32x16;
 #define MVIT_GEMM_MI16 1  // measurement builds: bit 1 the 8-wave 256x256 tile too, bit 2 the 4-wave 256-row tiles too
 #endif
@@ -716,7 +719,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     const int em0 = m0, en0 = n0;
     const int vt_next = vt + gridDim.x;
     const bool has_next = vt_next < ntiles;
-    if (has_next) {
+    // hipcc puts `s_waitcnt vmcnt(0)` in front of the first LDS read that follows an LDS-DMA builtin (it cannot tell the DMA's target
+    // from the panel), so with the prologue issued here the first slab of the epilogue waits for it to land.  Issuing it behind the
+    // first slab instead (LATE_PROLOGUE) was measured: qkv 75.6 vs 79.6 us and fc1 137.8 vs 141.6 us alone, but 427.8 vs 430.0
+    // tiles/s inside the step (same box) -- the earlier request is worth more there than the wait costs.  Off.
+    constexpr bool LATE_PROLOGUE = MVIT_GEMM_LATE_PROLOGUE && !TRANS;
+    if (has_next && (!LATE_PROLOGUE || (p.flags & 0x800))) {
       setup_tile(vt_next);
       issue_prologue(cb);
     }
@@ -1028,6 +1036,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
                 st8bf(Cb + (size_t)row * p.ldc + col, o_, nv);
               }
             }
+          }
+          if (LATE_PROLOGUE && slab == 0 && has_next) {   // (see above: the next tile's first K tiles, behind the first slab)
+            setup_tile(vt_next);
+            issue_prologue(cb);
           }
         }
     }
