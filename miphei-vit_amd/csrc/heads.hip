@@ -463,6 +463,8 @@ constexpr int CB_PART = CB_COLS * XC;       // floats per partial row
 constexpr int ET_STRIDE = 336;              // bytes per pixel row of the E tile (160 bf16 + pad: conflict-free 16-byte stores)
 
 constexpr int DZ_BLOCKS = 2048;   // grid cap of conv_bwd_dz_kernel = rows of its per-block db3 partials
+// FULL: NH == MAXH, no per-head bounds test around the loads (with it hipcc waits for each head's pair of loads before the next)
+template <bool FULL>
 __global__ __launch_bounds__(256) void conv_bwd_dz_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                           bf16_t* __restrict__ dzb, float* __restrict__ dbpart, int B,
                                                           long long HW, int NH) {
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256) void conv_bwd_dz_kernel(const float* __restric
 #pragma unroll
     for (int h = 0; h < MAXH; ++h) {
       dz[h] = 0.f;
-      if (h < NH) {
+      if (FULL || h < NH) {
         const size_t i = ((size_t)b * NH + h) * HW + pix;
         const float yy = Y[i];
         dz[h] = dY[i] * (1.f - yy * yy);
@@ -1083,7 +1085,10 @@ MVIT_API int mvit_heads_conv_bwd(const float* dY, const float* Y, const void* x,
   float* part = (float*)((char*)scratch + ((size_t)M * MAXH * sizeof(bf16_t) + 255) / 256 * 256);
   float* dbpart = part + (size_t)CB_BLOCKS * CB_PART;
   const int dzblocks = nblk(M, 256, DZ_BLOCKS);
-  hipLaunchKernelGGL(conv_bwd_dz_kernel, dim3(dzblocks), dim3(256), 0, s, dY, Y, dzb, dbpart, B, (long long)H * W, NH);
+  if (NH == MAXH)
+    hipLaunchKernelGGL(conv_bwd_dz_kernel<true>, dim3(dzblocks), dim3(256), 0, s, dY, Y, dzb, dbpart, B, (long long)H * W, NH);
+  else
+    hipLaunchKernelGGL(conv_bwd_dz_kernel<false>, dim3(dzblocks), dim3(256), 0, s, dY, Y, dzb, dbpart, B, (long long)H * W, NH);
   hipLaunchKernelGGL(conv_bwd_kernel, dim3(CB_BLOCKS), dim3(256), 0, s, (const bf16_t*)dzb, (const bf16_t*)x, (const bf16_t*)G, W3,
                      dG, dXc, part, B, H, W, NH);
   hipLaunchKernelGGL(conv_bwd_dw3_kernel, dim3((NH * 9 * XC + 255) / 256), dim3(256), 0, s, (const float*)part, dW3, NH, CB_BLOCKS,
