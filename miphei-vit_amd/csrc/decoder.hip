@@ -388,23 +388,34 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __
     }
   }
   __syncthreads();
+  // a thread keeps ONE group of eight channels (as the reduce kernel): its per-channel coefficients live in registers,
+  //   dx = A * [a > 0] * g + P * x + Q,   A = gamma * rstd,  P = -A * rstd * s2,  Q = -A * (s1 - rstd * mean * s2),  a = x * scale + shift
+  // (per element the former loop fetched scale / shift / mean / rstd / gamma from memory: 40 scalar loads per 16-byte output)
   const int cv = C >> 3;
-  const long long total = M * cv;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c8 = (int)(i % cv);
-    const long long m = i / cv;
-    float g[8], xv[8];
-    unpack8(*(const uint4*)(dy + (size_t)m * ld_dy + c8 * 8), g);
-    unpack8(*(const uint4*)(x + (size_t)m * C + c8 * 8), xv);
-    drop8(drop, (unsigned long long)m * C + c8 * 8, g);
+  const int c8 = threadIdx.x % cv, rl = threadIdx.x / cv, rpb = 256 / cv;
+  float sc[8], sh[8], cA[8], cP[8], cQ[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c8 * 8 + j;
-      const float gg = (xv[j] * scale[c] + shift[c] > 0.f) ? g[j] : 0.f;
-      const float xh = (xv[j] - mean[c]) * rstd[c];
-      g[j] = gamma[c] * rstd[c] * (gg - s1s[c] - xh * s2s[c]);
+  for (int j = 0; j < 8; ++j) {
+    const int c = c8 * 8 + j;
+    const float r = rstd[c], a = gamma[c] * r;
+    sc[j] = scale[c], sh[j] = shift[c];
+    cA[j] = a;
+    cP[j] = -a * r * s2s[c];
+    cQ[j] = -a * (s1s[c] - r * mean[c] * s2s[c]);
+  }
+  if (rl < rpb) {
+    for (long long m = (long long)blockIdx.x * rpb + rl; m < M; m += (long long)gridDim.x * rpb) {
+      float g[8], xv[8];
+      unpack8(*(const uint4*)(dy + (size_t)m * ld_dy + c8 * 8), g);
+      unpack8(*(const uint4*)(x + (size_t)m * C + c8 * 8), xv);
+      drop8(drop, (unsigned long long)m * C + c8 * 8, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gg = (xv[j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;
+        g[j] = cA[j] * gg + (cP[j] * xv[j] + cQ[j]);
+      }
+      *(uint4*)(dx + (size_t)m * C + c8 * 8) = pack8f(g);
     }
-    *(uint4*)(dx + (size_t)m * C + c8 * 8) = pack8f(g);
   }
 }
 
@@ -601,7 +612,8 @@ MVIT_API int mvit_bn_relu_bwd_apply(const void* dy, int ld_dy, const void* x, co
                                     float drop_p, unsigned long long drop_seed, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || (C & 7) || C > 512 || (ld_dy & 7) || nslots <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return MVIT_EINVAL;
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(nblk(M * (C >> 3), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+  // (every block re-sums the statistic slots in its prologue: few, long-lived blocks)
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(nblk(M, (256 / (C >> 3)) * 8, 1024)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, ld_dy, (const bf16_t*)x, scale, shift, mean, rstd, gamma, stats, dgamma, dbeta,
                      (bf16_t*)dx, M, C, nslots, count, make_drop(drop_p, drop_seed));
   return MVIT_LAUNCH_CHECK();
