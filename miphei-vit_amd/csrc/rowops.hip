@@ -294,18 +294,24 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
   const bf16_t* wp = W + (size_t)(wok ? r16 : 0) * ldw + kq * 8;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const uint4 zero = make_uint4(0, 0, 0, 0);
+  const unsigned xmask = rok ? 0xffffffffu : 0u, wmask = wok ? 0xffffffffu : 0u;
   int k = wave * 32;                       // this wave's k-steps: wave, wave + 4, wave + 8, ...
   constexpr int U = 6;                     // k-steps in flight per wave (K = 1536: 12 per wave = two full rounds; 4 and 12 measure the same)
   for (; k + (U - 1) * 128 + 32 <= K; k += U * 128) {
+    // unconditional loads (the pointers of rows / adapter columns outside the problem were clamped to row 0 above), masked
+    // afterwards: `rok ? load : zero` makes hipcc branch around each load and wait for it (three round trips per six k-steps)
     uint4 xa[U], wb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      xa[u] = rok ? *(const uint4*)(xp + k + 128 * u) : zero;
-      wb[u] = wok ? *(const uint4*)(wp + k + 128 * u) : zero;
+      xa[u] = *(const uint4*)(xp + k + 128 * u);
+      wb[u] = *(const uint4*)(wp + k + 128 * u);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      xa[u].x &= xmask, xa[u].y &= xmask, xa[u].z &= xmask, xa[u].w &= xmask;
+      wb[u].x &= wmask, wb[u].y &= wmask, wb[u].z &= wmask, wb[u].w &= wmask;
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&xa[u], *(bf16x8*)&wb[u], acc, 0, 0, 0);
+    }
   }
   for (; k < K; k += 128) {
     const bool kok = k + kq * 8 < K;
