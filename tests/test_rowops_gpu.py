@@ -21,7 +21,8 @@ def _rand(*shape, scale=1.0, seed=0):
     return torch.randn(*shape, generator=g, device="cuda") * scale
 
 
-@pytest.mark.parametrize("M,D", [(7, 64), (329 * 2, 96), (1000, 1536)])
+# D = 512 / 1024 / 1536 / 2048 run the instantiations without per-group bounds tests (rows of whole float4 groups), the rest the generic ones
+@pytest.mark.parametrize("M,D", [(7, 64), (329 * 2, 96), (1000, 1536), (5, 512), (33, 1024), (9, 2048), (17, 1280), (3, 1540)])
 def test_layernorm_fwd_bwd(M, D):
     ops = _ops()
     x = _rand(M, D, seed=1) * 3 + 0.5
@@ -104,7 +105,7 @@ def test_patch_prefix_cast():
     assert torch.equal(o, (xx * gam).bfloat16())
 
 
-@pytest.mark.parametrize("M,D,r", [(7, 64, 4), (329 * 2, 96, 8), (5264, 1536, 8), (1301, 1536, 4)])
+@pytest.mark.parametrize("M,D,r", [(7, 64, 4), (329 * 2, 96, 8), (5264, 1536, 8), (1301, 1536, 4), (37, 512, 8), (21, 1024, 8), (19, 2048, 4), (23, 1280, 8)])
 def test_layernorm_lora_fused_matches_ln_then_matmul(M, D, r):
     """LN1 + the LoRA down-projection in one pass: h identical to the plain LN kernel, t = bf16(h) @ bf16([A_q|A_v])."""
     ops = _ops()
