@@ -171,7 +171,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       const int q = ntiles >> 3, r = ntiles & 7, xcd = vt & 7;
       wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
     }
-    constexpr int GROUP_M = BM >= 256 ? 4 : 8;
+    // tile rows per group of the tile order (256-row tiles): 8 since round 3 -- re-measured on the 16x16x32 kernels, same box, three
+    // pairs of runs each: 8 vs 4 +0.45 % (451.5 vs 449.4 tiles/s), 16 vs 8 -0.1 %
+#ifndef MVIT_GEMM_GROUP_M
+#define MVIT_GEMM_GROUP_M 8
+#endif
+    constexpr int GROUP_M = BM >= 256 ? MVIT_GEMM_GROUP_M : 8;
     const int per_group = GROUP_M * tiles_n;
     const int first_m = (wg / per_group) * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
