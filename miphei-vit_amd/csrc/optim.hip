@@ -49,14 +49,24 @@ __global__ __launch_bounds__(256) void wmse_kernel(const float* __restrict__ pre
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, double* __restrict__ out, long long n) {
   __shared__ double sh[4];
   double acc = 0.;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
-    if (i + 3 < n) {
-      const float4 a = *(const float4*)(x + i);
-      acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
-    } else {
-      for (long long j = i; j < n; ++j) acc += (double)x[j] * x[j];
-    }
+  // four unguarded 16-byte loads per trip while they all fit (a bounds test around each load makes hipcc wait for it before the
+  // next one: 26 dependent round trips per thread at the 6.7 M trainable parameters), then single groups, then the ragged end
+  const long long stride = (long long)gridDim.x * 1024;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (; i + 3 * stride + 3 < n; i += 4 * stride) {
+    const float4 a = *(const float4*)(x + i), b = *(const float4*)(x + i + stride), c = *(const float4*)(x + i + 2 * stride),
+                 d = *(const float4*)(x + i + 3 * stride);
+    acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
+    acc += (double)(b.x * b.x + b.y * b.y) + (double)(b.z * b.z + b.w * b.w);
+    acc += (double)(c.x * c.x + c.y * c.y) + (double)(c.z * c.z + c.w * c.w);
+    acc += (double)(d.x * d.x + d.y * d.y) + (double)(d.z * d.z + d.w * d.w);
   }
+  for (; i + 3 < n; i += stride) {
+    const float4 a = *(const float4*)(x + i);
+    acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
+  }
+  if (i < n)
+    for (long long j = i; j < n; ++j) acc += (double)x[j] * x[j];
   const double r = block_sum_d(acc, sh);
   if (threadIdx.x == 0) atomicAdd(out, r);
 }
@@ -65,14 +75,24 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, long long n) {
   __shared__ double sh[4];
   double acc = 0.;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
-    if (i + 3 < n) {
-      const float4 a = *(const float4*)(x + i);
-      acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
-    } else {
-      for (long long j = i; j < n; ++j) acc += (double)x[j] * x[j];
-    }
+  // four unguarded 16-byte loads per trip while they all fit (a bounds test around each load makes hipcc wait for it before the
+  // next one: 26 dependent round trips per thread at the 6.7 M trainable parameters), then single groups, then the ragged end
+  const long long stride = (long long)gridDim.x * 1024;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (; i + 3 * stride + 3 < n; i += 4 * stride) {
+    const float4 a = *(const float4*)(x + i), b = *(const float4*)(x + i + stride), c = *(const float4*)(x + i + 2 * stride),
+                 d = *(const float4*)(x + i + 3 * stride);
+    acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
+    acc += (double)(b.x * b.x + b.y * b.y) + (double)(b.z * b.z + b.w * b.w);
+    acc += (double)(c.x * c.x + c.y * c.y) + (double)(c.z * c.z + c.w * c.w);
+    acc += (double)(d.x * d.x + d.y * d.y) + (double)(d.z * d.z + d.w * d.w);
   }
+  for (; i + 3 < n; i += stride) {
+    const float4 a = *(const float4*)(x + i);
+    acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
+  }
+  if (i < n)
+    for (long long j = i; j < n; ++j) acc += (double)x[j] * x[j];
   const double r = block_sum_d(acc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }

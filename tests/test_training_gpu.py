@@ -91,3 +91,15 @@ def test_lora_group_size_does_not_change_gradients():
     assert noise < 0.05
     for g in grads[2:]:
         assert _rel(g, grads[0]) < max(3 * noise, 1e-3)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 262144 * 4 + 5, 6_697_712, 6_697_713])
+def test_squared_norm_kernel_any_length(n):
+    """mvit_sqnorm over lengths around its unrolled trips (four 16-byte groups, single groups, ragged end): f64 sum of squares"""
+    import miphei_vit_amd.ops as ops
+    g = torch.Generator(device="cuda").manual_seed(n % 1000)
+    x = torch.randn(n + 3, device="cuda", generator=g)[:n]          # (a view: same alignment as the allocation)
+    out = torch.full((1,), 2.5, device="cuda", dtype=torch.float64)
+    ops.sqnorm(x, out)
+    ref = 2.5 + float((x.double() ** 2).sum())
+    assert abs(float(out) - ref) < 2e-6 * max(1.0, abs(ref))      # (pairs of squares are added in f32 before the f64 accumulation)
