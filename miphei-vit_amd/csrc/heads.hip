@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const bf16_t* __restri
         a = mfma(frag_lo(wbias[blk]), ones, a);
         float r[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) r[j] = fmaxf(a[j], 0.f);
+        for (int j = 0; j < 16; ++j) r[j] = __int_as_float(max(__float_as_int(a[j]), 0));   // ReLU as ONE v_max_i32 (fmaxf is two v_max_f32: the kernel is VALU-bound)
         psi = mfma(w2s[2 * blk][lane], frag8(r), psi);
         psi = mfma(w2s[2 * blk + 1][lane], frag8(r + 8), psi);
       }
