@@ -36,6 +36,9 @@ FLOPS_ENC = {256: 773.6e9}                       # encoder only (patch embed + 4
 ORION_MARKERS = ["Hoechst", "CD31", "CD45", "CD68", "CD4", "FOXP3", "CD8a", "CD45RO", "CD20", "PD-L1", "CD3e", "CD163",
                  "E-cadherin", "Ki67", "Pan-CK", "SMA"]
 PEAK_BF16 = 2.5e15                                # dense MFMA bf16, MI355X_MICROARCH.md
+# second, explicitly labelled denominator: what a loop of nothing but v_mfma_f32_16x16x32_bf16 on random register operands sustains at
+# the socket power cap (tools/probes/mfma_power.hip, profiles/README.md: 2033.7 TF/s) -- `peak` stays the nominal 2.5 PF
+SUSTAINED_BF16 = 2.03e15
 
 
 from miphei_vit_amd.synthetic import synthetic_batch, synthetic_init_  # noqa: E402,F401  (kept importable as bench.*)
@@ -265,13 +268,20 @@ def main(argv=None):
     # roofline leg: HIP events around the launches of the dominant kernel, on a SAMPLE of the timed steps (every probe_every-th,
     # at least one): an event pair costs the stream ~6 us of idle time per launch, which on all 159 launches of every step was
     # 2.9 % of the headline number (395 vs 406.5 tiles/s same box)
+    # Round 4: the probe samples TWO of the timed steps (the first and the middle one: 318 launches), and one event per step
+    # boundary (a marker every ~36 ms) gives the duration of every step, so the line also carries the rate of the unprobed steps
+    # (`unprobed`): at the driver's --steps 20 the former five sampled steps cost ~0.7 % of the headline, two cost ~0.25 %.
     ops.PROBE.start()
     ops.PROBE.on = False
-    probe_every = max(1, a.steps // 5)
+    probed = sorted({0, a.steps // 2}) if a.probe else []
+    probe_every = max(1, a.steps // 2)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
-        ops.PROBE.on = bool(a.probe) and (i % probe_every == 0)
+        ops.PROBE.on = i in probed
         step(a.warmup + i)
+        marks[i + 1].record()
     ops.PROBE.on = True
     torch.cuda.synchronize()
     if world > 1:
@@ -279,6 +289,8 @@ def main(argv=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     probe = ops.PROBE.stop()
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    free_ms = [t for i, t in enumerate(step_ms) if i not in probed] or step_ms
     comm = (sync.exposed_ms(), sync.bucket_report()) if (sync is not None and a.mode == "train") else None   # timed steps only
     kernels = None
     if a.probe and a.mode == "train":       # (every rank: the extra steps run the gradient exchange too)
@@ -313,6 +325,10 @@ def main(argv=None):
                                ("(SURVEY.md 8f row 4)" if a.mode == "embed" or unet else f"(BASELINE.json configs[{cfg_idx}])"),
                    "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}", "pix_metrics": bool(a.metrics)},
     }
+    res["unprobed"] = {"ms_per_step": round(sum(free_ms) / len(free_ms), 3), "tiles_per_s": round(a.batch * world * len(free_ms) / (sum(free_ms) * 1e-3), 2),
+                       "steps": len(free_ms), "probed_steps": len(probed),
+                       "note": "this rank's timed steps that carried no HIP-event probe (step-boundary events on the compute stream); "
+                               "`value` is the contract number over ALL timed steps, probe overhead included"}
     if dist.is_initialized():
         res["rccl_ranks"] = dist.get_world_size()
         if comm is not None:
@@ -345,14 +361,16 @@ def main(argv=None):
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16, 4), "traffic": traffic, "traffic_source": src,
                                "launches": probe["n"], "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2),
-                               "sampled_steps": len(range(0, a.steps, probe_every)),
+                               "sampled_steps": len(probed),
+                               "peak_sustained": SUSTAINED_BF16 / 1e12, "frac_of_sustained": round(ach / SUSTAINED_BF16, 4),
                                "note": "HIP events on the stream around every launch of this kernel in the sampled timed steps"}
         if kernels:
             tot_ms = sum(v["ms"] for v in kernels.values())
             rk = []
+            traf = pmc_traffic_all()
             for key, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
                 ach = v["flops"] / (v["ms"] * 1e-3)
-                rk.append({"kernel": key, "launches_per_step": v["n"] // 2, "gflop_per_launch": round(v["flops"] / v["n"] / 1e9, 2),
+                rk.append({"kernel": key, "traffic": traf.get(_pmc_key(key)), "launches_per_step": v["n"] // 2, "gflop_per_launch": round(v["flops"] / v["n"] / 1e9, 2),
                            "avg_us": round(v["ms"] * 1e3 / v["n"], 1), "achieved": round(ach / 1e12, 1),
                            "frac": round(ach / PEAK_BF16, 4), "ms_per_step": round(v["ms"] / 2, 3)})
             res["roofline_kernels"] = {"bound": "mfma", "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "kernels": rk,
@@ -380,12 +398,43 @@ def main(argv=None):
     return 0
 
 
+def _pmc_key(kprobe_name):
+    """name of a KPROBE entry as rocprofv3 spells the kernel: 'mvit_gemm::gemm_kernel<256,128,4,2,DENSE,RESID>' ->
+    'gemm_kernel<256, 128, 4, 2, 0, 3>'; the attention entries are spelled as KPROBE spells them (backward = sum of its launches)"""
+    epi = {"STORE": 0, "GELU": 1, "SWIGLU": 2, "RESID": 3, "PATCH": 4, "STATS": 5, "DSWIGLU": 6, "DGELU": 7}
+    if "gemm_kernel<" in kprobe_name:
+        f = kprobe_name.split("<", 1)[1].rstrip(">").split(",")
+        return "gemm_kernel<%s, %s, %s, %s, 0, %d>" % (f[0], f[1], f[2], f[3], epi.get(f[5], -1))
+    return kprobe_name
+
+
+def pmc_traffic_all():
+    """{kernel key: HBM-side bytes per launch} of the newest committed PMC summary (see pmc_traffic)."""
+    out = {}
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                k = json.load(f)["kernels"]
+        except Exception:  # noqa: BLE001
+            continue
+        for kn, v in k.items():
+            key = kn.replace("void ", "").replace("mvit_gemm::", "").strip()
+            out[key] = round(v["hbm_bytes_per_launch_corrected"])
+        if "attn_bwd_dq_kernel" in out and "attn_bwd_dkv_kernel" in out:
+            out["attn_bwd (all launches of mvit_attention_bwd)"] = sum(v for kk, v in out.items() if kk.startswith("attn_bwd_"))
+        return out
+    return out
+
+
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
 def pmc_traffic():
     """(HBM-side bytes per launch of the dominant kernel, where the figure comes from).  The PMC counters cannot be read from
     inside the timed run: the value is the committed rocprofv3 summary of this same command (separate FETCH_SIZE / WRITE_SIZE
     passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of MI355X_MICROARCH.md; L2-side fabric requests, so
     Infinity-Cache hits are included), newest round first.  (None, None) when no summary is present."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in PMC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 k = json.load(f)["kernels"]

@@ -123,6 +123,8 @@ class CellMetrics:
         kept = [(i, n) for i, n in enumerate(marker_names) if n not in excluded]
         self.marker_names = [n for _, n in kept]
         self.marker_idxs = [i for i, _ in kept]
+        self.marker_cols = [f"{n}_pos" for n in self.marker_names]          # reference metrics.py:21-22 (ModelModule sizes its
+        self.marker_pred_cols = [f"{n}_pred" for n in self.marker_names]    # logreg_layer from them, models.py:57-59)
         self.min_area = min_area
         self.slide_names = list(slide_names)
         self.state = {s: {"cell_id": [], "sum": [], "area": []} for s in self.slide_names}

@@ -40,14 +40,23 @@ class ModelModule(_Base):
         if gan_train or discriminator is not None and gan_train:
             raise NotImplementedError("the PatchGAN branch is outside the MI355X hot path (gan_train: false is the "
                                       "MIPHEI-ViT default)")
-        if cell_metrics is not None or cell_loss is not None:
-            raise NotImplementedError("cell-level metrics / losses are outside the MI355X hot path")
+        if cell_loss is not None:
+            raise NotImplementedError("the cell-level LOSS (reference models.py:236-240, a training objective through "
+                                      "MeanCellExtrator) is outside the MI355X hot path; cell_metrics (validation) is supported")
+        if cell_metrics is not None and not callable(getattr(cell_metrics, "update", None)):
+            raise TypeError("cell_metrics must expose update(preds, nuclei_masks, slide_names) (cells.CellMetrics)")
         self.generator = generator
         self.foreground_head = hasattr(generator, "foreground_head")
         self.discriminator = None
         self.gan_train = False
         self.automatic_optimization = False
-        self.use_cell_metrics = False
+        # validation-time per-nucleus statistics (reference models.py:54-61, 233-241): the segmented-reduction extractor of
+        # csrc/cells.hip behind cells.CellMetrics.update; its sklearn-side ``compute`` stays evaluation code
+        self.use_cell_metrics = cell_metrics is not None
+        self.cell_metrics = cell_metrics
+        self.cell_loss = None
+        if self.use_cell_metrics and hasattr(cell_metrics, "marker_pred_cols") and hasattr(cell_metrics, "marker_cols"):
+            self.logreg_layer = nn.Linear(len(cell_metrics.marker_pred_cols), len(cell_metrics.marker_cols))
         self.lr_g, self.lr_d = lr_g, lr_d
         self.loss_reconstruct = loss_reconstruct
         self.vit_lr_decay = False
@@ -235,7 +244,9 @@ class ModelModule(_Base):
         with torch.no_grad():
             out = self.generator(batch["image"])
             y = batch["target"].to(out.device)
-            if self.update_pix_metrics:  # reference evaluation_step, models.py:294-296
+            if self.use_cell_metrics:    # reference evaluation_step, models.py:233-241
+                self.cell_metrics.update(out, batch["nuclei"].to(out.device), batch["slide_name"])
+            if self.update_pix_metrics:  # reference evaluation_step, models.py:258-261
                 metrics.update(out, y)
             return self.loss_reconstruct(y, out)
 

@@ -5,7 +5,12 @@
 
 Mirrors ``/root/reference/run.py`` + ``src/train.py:34-210`` for the parts on the MI355X hot path: compose the config,
 build generator / loss / ``ModelModule``, run the (fused) training steps, save ``model.safetensors`` (LoRA + decoder) with
-the reference key names.  Data loading is outside the path: tiles are synthetic and generated on the device.
+the reference key names.  Data loading is outside the path: tiles are synthetic and generated on the device, or -- with
+``++data.uint8_tiles=<tiles.npz>`` (arrays ``image`` [N,H,W,3] and ``target`` [N,H,W,C], uint8) -- a tile set resident in HBM
+that goes through the on-device input stage every step (``io_stage.TrainAugmenter``: RandomCrop / flips / CoarseDropout +
+both normalisations, the reference's ``dataset.py:244-311, 458-483`` without the CPU loader).  ``++data.val_uint8_tiles=<val.npz>``
+(``image``, ``target`` and, for ``train.use_cell_metrics``, ``nuclei`` [N,H,W] int32 + ``slide_name`` [N]) runs
+``ModelModule.validation_step`` over that set after training, as ``src/train.py:111-114`` + ``models.py:233-241, 290-291`` do.
 """
 import os
 import sys
@@ -37,8 +42,8 @@ def main(argv):
     if (losses.get("cell_loss") or {}).get("use_loss"):
         raise NotImplementedError("train.losses.cell_loss.use_loss: the cell-level loss (reference src/train.py:144-150) is "
                                   "outside the MI355X hot path")
-    # (train.use_cell_metrics -- on in the reference's shipped recipes through train=cell -- only adds validation-time CellMetrics
-    # (src/train.py:111-114, models.py:233-241); run.py runs training steps only, the extractor lives in miphei_vit_amd.cells)
+    # (train.use_cell_metrics -- on in the reference's shipped recipes through train=cell -- adds validation-time CellMetrics
+    # (src/train.py:111-114, models.py:233-241): built below when a validation tile set with nuclei masks is given)
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     # MIPHEI_DIST_BACKEND=gloo MIPHEI_SHARE_GPU=1: rehearsal of the multi-rank branch on a one-GPU box (RCCL refuses two ranks
     # on one device; gloo takes device tensors): every rank uses cuda:0.  The product transport is RCCL ("nccl").
@@ -64,8 +69,25 @@ def main(argv):
         stats_path = os.path.join(ROOT, stats_path)
     weights = marker_weights_from_file(stats_path, cfg.data.targ_channel_names)   # train.py:137-142
     loss = WeightedMSELoss(cfg.train.losses.lambda_factor, weights)
+    # resident uint8 tile sets (the arrays are small enough for HBM by construction: 288 GB hold ~230 k ORION tiles)
+    import numpy as np
+    tiles = val_tiles = None
+    if cfg.data.get("uint8_tiles"):
+        z = np.load(cfg.data.uint8_tiles)
+        tiles = (torch.from_numpy(z["image"]).to(dev), torch.from_numpy(z["target"]).to(dev))
+        if tiles[0].dtype != torch.uint8 or tiles[0].shape[3] != 3 or tiles[1].shape[3] != nc or min(tiles[0].shape[1:3]) < S:
+            raise ValueError(f"data.uint8_tiles: need uint8 image [N,H,W,3] and target [N,H,W,{nc}] with H, W >= {S}")
+    cell_metrics = None
+    if cfg.data.get("val_uint8_tiles"):
+        z = np.load(cfg.data.val_uint8_tiles)
+        val_tiles = {k: z[k] for k in z.files}
+        if cfg.train.get("use_cell_metrics"):        # src/train.py:111-114
+            from miphei_vit_amd.cells import CellMetrics
+            if "nuclei" not in val_tiles or "slide_name" not in val_tiles:
+                raise ValueError("train.use_cell_metrics needs nuclei and slide_name arrays in data.val_uint8_tiles")
+            cell_metrics = CellMetrics(sorted(set(str(s_) for s_ in val_tiles["slide_name"])), list(cfg.data.targ_channel_names))
     module = ModelModule(generator, None, cfg.train.learning_rate_g * B ** 0.5, cfg.train.learning_rate_d, loss,
-                         gan_train=cfg.train.gan_train).to(dev)
+                         cell_metrics=cell_metrics, gan_train=cfg.train.gan_train).to(dev)
     steps = int(cfg.train.max_steps)
     module.total_iters = steps
     if world > 1:
@@ -83,10 +105,22 @@ def main(argv):
         if rank == 0:
             print(f"resumed from {resume} at step {start} (LR horizon {module.total_iters} steps)", flush=True)
     every = int(cfg.train.get("checkpoint_every") or 0)
+    augment = None
+    if tiles is not None:
+        from miphei_vit_amd.io_stage import TrainAugmenter
+        # counter-based draws: sample n of the run is global (step * world * B + rank * B + b), so a rank layout change does not
+        # change what a sample looks like
+        augment = TrainAugmenter(dev, (S, S), seed=int(cfg.train.get("seed") or 0))
     t0 = time.perf_counter()
     for i in range(start, steps):
-        x, y = synthetic_batch(1234 + rank * 1000 + i, B, S, nc, dev)
-        out = module.training_step({"image": x, "target": y}, i)
+        if augment is not None:
+            n0 = (i * world + rank) * B
+            idx = (torch.arange(n0, n0 + B, device=dev) % tiles[0].shape[0])
+            batch = augment(tiles[0][idx], tiles[1][idx], n0)
+        else:
+            x, y = synthetic_batch(1234 + rank * 1000 + i, B, S, nc, dev)
+            batch = {"image": x, "target": y}
+        out = module.training_step(batch, i)
         if rank == 0 and (i % 10 == 0 or i == steps - 1):
             print(f"step {i:5d}  loss {float(out):.4f}  lr {module.current_lr(i):.3e}", flush=True)
         if rank == 0 and every and (i + 1) % every == 0 and i + 1 < steps:
@@ -95,6 +129,24 @@ def main(argv):
             save_checkpoint_atomic(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
     module.on_train_end()           # drains the asynchronous NaN guard
     torch.cuda.synchronize()
+    if val_tiles is not None and rank == 0:
+        from miphei_vit_amd.io_stage import InputStage
+        stage = InputStage(dev)
+        vi, vt = torch.from_numpy(val_tiles["image"]).to(dev), torch.from_numpy(val_tiles["target"]).to(dev)
+        if vi.shape[1] != S or vi.shape[2] != S:
+            raise ValueError(f"data.val_uint8_tiles: validation tiles must be {S}x{S} (the reference centre-crops on the CPU)")
+        losses_v = []
+        for j0 in range(0, vi.shape[0], B):
+            vb = {"image": stage.image(vi[j0:j0 + B].contiguous()), "target": stage.target(vt[j0:j0 + B].contiguous())}
+            if module.use_cell_metrics:
+                vb["nuclei"] = torch.from_numpy(val_tiles["nuclei"][j0:j0 + B].astype("int32")).to(dev)
+                vb["slide_name"] = [str(s_) for s_ in val_tiles["slide_name"][j0:j0 + B]]
+            losses_v.append(float(module.validation_step(vb, j0 // B)))
+        msg = f"validation: {vi.shape[0]} tiles, val_gen_loss_sim {sum(losses_v) / len(losses_v):.4f}"
+        if module.use_cell_metrics:
+            n_cells = sum(int(t.numel()) for st in module.cell_metrics.state.values() for t in st["cell_id"])
+            msg += f", cell_metrics: {n_cells} nuclei over {len(module.cell_metrics.state)} slides"
+        print(msg, flush=True)
     if rank == 0:
         dt = time.perf_counter() - t0
         print(f"{steps - start} steps, {world * B * (steps - start) / dt:.1f} tiles/s")

@@ -12,7 +12,8 @@ def _rel(a, b):
     return float(((a - b) ** 2).sum().sqrt() / b.pow(2).sum().sqrt().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("B,N,H,Dh", [(2, 329, 3, 64), (1, 69, 4, 16), (2, 86, 3, 32), (1, 1301, 2, 64), (3, 128, 2, 64)])
+@pytest.mark.parametrize("B,N,H,Dh", [(2, 329, 3, 64), (1, 69, 4, 16), (2, 86, 3, 32), (1, 1301, 2, 64), (3, 128, 2, 64),
+                                       (2, 329, 24, 64)])      # the last one: H-Optimus-0's own head count (24-head stride pattern of the packed qkv)
 def test_attention_fwd_bwd(B, N, H, Dh):
     import miphei_vit_amd.ops as ops
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + N)

@@ -58,3 +58,50 @@ def test_deterministic_mode_gives_bit_identical_steps(cfgname, img, nc, B):
     assert abs(la - lb) <= 1e-12 * abs(la)   # (the reported loss value alone still meets in f64 atomics: last-digit differences)
     c, lc = _run(False, (cfgname, img, nc, B))
     assert abs(lc - la) < 2e-3 * abs(la)  # the default mode computes the same step (atomics: not bit-identical, not asserted)
+
+
+SCRIPT_FULL = r'''
+import hashlib, sys
+import torch
+sys.path.insert(0, %r)
+import bench
+from oracle.model import orion_marker_weights
+from miphei_vit_amd import ops
+from miphei_vit_amd.generators import get_vitmatte
+from miphei_vit_amd.loss import WeightedMSELoss
+from miphei_vit_amd.models import ModelModule
+B, nc, img = int(sys.argv[1]), 16, 256
+dev = torch.device("cuda:0")
+with torch.device(dev):
+    model = get_vitmatte("hoptimus0", img, nc, use_lora=True, pretrained=False)
+bench.synthetic_init_(model, seed=13)        # (device generator: the same stream in every process on the same device type)
+mod = ModelModule(model, None, 1e-3, 0., WeightedMSELoss(50.0, orion_marker_weights(nc))).to(dev)
+mod.total_iters, mod.global_step_ = 4000, 1000
+mod.update_pix_metrics = False
+h = hashlib.sha256()
+for it in range(2):
+    x, y = bench.synthetic_batch(300 + it, B, img, nc, dev)
+    loss = mod.training_step({"image": x, "target": y}, it)
+    h.update(model._engine._flat.gflat.cpu().numpy().tobytes())
+    h.update(model._engine._flat.flat.cpu().numpy().tobytes())
+for k, v in sorted(model.state_dict().items()):
+    if "running_" in k:
+        h.update(v.detach().float().cpu().numpy().tobytes())
+print("DET", int(ops.DETERMINISTIC), h.hexdigest(), float(loss))
+''' % ROOT
+
+
+def test_deterministic_mode_on_the_benchmark_configuration():
+    """H-Optimus-0 at batch 16 (BASELINE configs[1]): the ordered reductions on the 256-row GEMM tiles, the 40-block backward with
+    its batched LoRA products and the full-size decoder -- two steps, two processes, identical bytes."""
+    def run():
+        env = dict(os.environ, MIPHEI_DETERMINISTIC="1")
+        p = subprocess.run([sys.executable, "-c", SCRIPT_FULL, "16"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("DET")][-1].split()
+        assert int(line[1]) == 1
+        return line[2], float(line[3])
+    a, la = run()
+    b, lb = run()
+    assert a == b
+    assert abs(la - lb) <= 1e-12 * abs(la)

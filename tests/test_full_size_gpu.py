@@ -47,8 +47,10 @@ def test_hoptimus0_forward_loss_gradnorm_vs_oracle(B, img):
     for k in ("decoder.segmentation_head_3.1.weight", "decoder.segmentation_head_0.0.psi.3.weight", "decoder.fusion_blks.3.conv.bn.weight"):
         g1, g0 = named[k].grad.double().cpu(), gref[k].double()
         assert float((g1 - g0).norm() / g0.norm()) < 0.05, k
-    if B != 2:
+    if img != 256:
         return
+    # (round 4: also at B = 16, the tile path the benchmark runs -- 256-row dgrad tiles, three attention row blocks per pair, the
+    # batched LoRA weight-gradient products over groups of 10 blocks)
     # Per-parameter gradients at full depth: LoRA A / B of blocks 0, 20, 39 (the far end, the middle and the near end of the
     # 40-block backward chain: a wrong stride or a dropped term in ANY block's dgrad chain shows up at block 0) and EVERY decoder
     # gradient.  Yardstick: the same arithmetic under bf16 autocast on the CPU (the reference's mixed-precision mode,
@@ -65,9 +67,11 @@ def test_hoptimus0_forward_loss_gradnorm_vs_oracle(B, img):
     bad, rows = {}, []
     for k in keys:
         gr, got = gref[k], named[k].grad.detach().cpu()
-        if float(gr.double().norm()) < 1e-5 * gnorm:      # analytically zero (conv bias in front of a train-mode BatchNorm)
+        if ".lora_" not in k and float(gr.double().norm()) < 1e-5 * gnorm:   # analytically zero (conv bias in front of a train-mode BatchNorm)
             assert float(got.double().norm()) < 1e-5 * gnorm, k
             continue
+        # (LoRA tensors are never skipped: every criterion below is relative to the tensor's own norm, however small a share of the
+        # global norm a deep adapter's gradient is)
         e_hip, e_ac, c_hip, c_ac = rel(got, gr), rel(gac[k], gr), cosf(got, gr), cosf(gac[k], gr)
         rows.append((k, e_hip, e_ac, c_hip, c_ac))
         if e_hip > max(1.25 * e_ac, 0.02) or c_hip < min(0.999, c_ac - 0.002):
@@ -78,7 +82,7 @@ def test_hoptimus0_forward_loss_gradnorm_vs_oracle(B, img):
         print("  %-48s %.4f %.4f %.5f %.5f" % r)
     worst = max(rows, key=lambda r: r[1] / max(r[2], 0.016))
     print("worst decoder/LoRA ratio: %s %.4f vs %.4f" % worst[:3])
-    assert len(lora) >= 8 and not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12]    # (some dA at depth are below 1e-5 of the total norm)
+    assert len(lora) == 12 and not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12]
 
 
 @pytest.mark.parametrize("B", [16, 64])   # 64 = BASELINE configs[4] (inference): fc1 runs the 256x256 tile there
