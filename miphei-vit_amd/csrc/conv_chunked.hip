@@ -421,7 +421,10 @@ MVIT_API int mvit_conv3x3_chunked(const void* X, const void* Wp, void* Y, double
   static mvit_per_device_size raised;
   if (mvit_ensure_dynamic_lds((const void*)conv3x3_chunked_kernel, CC_LDS, raised) != MVIT_OK) return MVIT_EINVAL;
   const long long items = (long long)B * ((H + CC_TH - 1) / CC_TH) * ((W + CC_TW - 1) / CC_TW) * ((Cout + CC_NS - 1) / CC_NS);
-  const int blocks = items < mvit_num_cus() ? (int)items : mvit_num_cus();      // one persistent block per CU (LDS)
+  int blocks = items < mvit_num_cus() ? (int)items : mvit_num_cus();            // one persistent block per CU (LDS)
+  // >= 256 statistic slots = the deterministic mode's "one writer block per slot" contract (slot = blockIdx.x % nslots): keep it on
+  // parts with more CUs than slots, as launch_one of gemm_kernel.hpp does for its STATS epilogue
+  if (stats && nslots >= 256 && blocks > nslots) blocks = nslots;
   hipLaunchKernelGGL(conv3x3_chunked_kernel, dim3(blocks), dim3(256), CC_LDS, (hipStream_t)stream, a);
   return MVIT_LAUNCH_CHECK();
 }

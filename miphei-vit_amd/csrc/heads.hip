@@ -319,6 +319,9 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const bf16_t* __restri
         float r[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) r[j] = __int_as_float(max(__float_as_int(a[j]), 0));   // ReLU as ONE v_max_i32 (fmaxf is two v_max_f32: the kernel is VALU-bound)
+        // (non-finite inputs: -0.0 and every negative float compare below integer 0 -> 0, as fmaxf; a NaN keeps its payload if its sign
+        //  bit is clear and becomes 0 if it is set -- NaN handling in the gate is UNSPECIFIED, the step's NaN guard is the gradient norm
+        //  in optim.hip, which any NaN upstream of the gate reaches through the encoder's shared feature map)
         psi = mfma(w2s[2 * blk][lane], frag8(r), psi);
         psi = mfma(w2s[2 * blk + 1][lane], frag8(r + 8), psi);
       }

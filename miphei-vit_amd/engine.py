@@ -405,7 +405,10 @@ class HipEngine:
         w.t = list(w.t_all.unbind(0)) if c.lora else None
         w.qkv = [e(M, 3 * D) for _ in range(nl)]
         w.o = [e(M, D) for _ in range(nl)]
-        w.ores = [e(M, D) for _ in range(nl)] if train else None   # bf16 rounding residual of o (D term of the attention backward)
+        # bf16 rounding residual of o (D term of the attention backward): allocated by the first training forward that runs with
+        # attn_residual on (650 MB at B = 16 / 40 blocks), see _attn_res()
+        w.ores = None
+        w.ores_on = False     # latched by every forward: the backward reads the residual iff the forward of THIS step wrote it
         w.lse = [e(B, c.H, c.ntok, dt=torch.float32) for _ in range(nl)]
         w.u = [e(M, c.hidden) for _ in range(nl)] if train else None
         w.g = e(M, c.Hg)
@@ -421,6 +424,11 @@ class HipEngine:
         w.feat = e(B, G, G, D)
         w.cat = [e(B, s3, s3, CONV_CH[3] + D), e(B, s2, s2, CONV_CH[2] + FUS_OUT[0]), e(B, s1, s1, CONV_CH[1] + FUS_OUT[1]),
                  z(B, S, S, _pad8(CONV_CH[0] + FUS_OUT[2]))]
+        if max(t.numel() for t in w.cat) * 2 >= 2 ** 31:
+            # the decoder kernels address their NHWC buffers with 32-bit byte offsets (raw buffer descriptors); the implicit-GEMM
+            # fallback has the same limit and its weight layouts are not even packed when the chunked kernels are on
+            raise ValueError(f"decoder buffers of batch {B} at {S}x{S} exceed the 2 GiB range of 32-bit buffer offsets: split the "
+                             "batch (at most 372 tiles at 256 px, 93 at 512 px)")
         w.pre_c = [e(B * s1 * s1, 48), e(B * s2 * s2, 96), e(B * s3 * s3, 192)]
         w.pre_f = [e(B * s3 * s3, 256), e(B * s2 * s2, 128), e(B * s1 * s1, 64), e(B * S * S, 32)]
         w.F3 = e(B * S * S, HEAD_C)
@@ -512,6 +520,18 @@ class HipEngine:
         draw = (torch.rand(c.L, 2, w.B, device=w.tok.device) < keep).float() / keep
         return draw.repeat_interleave(c.ntok, dim=2).contiguous()
 
+    def _attn_res(self, w, i, train):
+        """residual buffer of block i for this forward (None = off).  The A/B switch ``attn_residual`` is latched per forward in
+        ``w.ores_on`` so that a toggle between forward and backward cannot make the backward read an unwritten residual."""
+        on = bool(train and self.attn_residual)
+        if i == 0:
+            w.ores_on = on
+        if not w.ores_on:
+            return None
+        if w.ores is None:
+            w.ores = [torch.empty(w.M, self._config().D, device=w.tok.device, dtype=torch.bfloat16) for _ in range(len(w.o))]
+        return w.ores[i]
+
     def _encoder_fwd(self, w, x, train, pk, taps=None, img8=None):
         """taps: {block index: bf16 [M, D] buffer} receives the residual stream after that block (forward_intermediates);
         img8: bf16 NHWC [B,S,S,8] image already written by the input stage (else converted from x here)"""
@@ -549,7 +569,7 @@ class HipEngine:
             else:
                 ops.layernorm_fwd(xin, b.n1w, b.n1b, w.h1[i], c.eps)
                 ops.gemm(w.h1[i], b.wqkv, w.qkv[i], bias=b.bqkv)
-            ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[i] if (train and self.attn_residual) else None)
+            ops.attention_fwd(w.qkv[i], w.o[i], w.lse[i], B, c.ntok, c.H, c.Dh, scale, out_res=self._attn_res(w, i, train))
             ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32,
                      rowscale=None if dp is None else dp[l, 0])
             ops.layernorm_fwd(xmid, b.n2w, b.n2b, w.h2, c.eps)
@@ -846,7 +866,7 @@ class HipEngine:
             # attention branch: dy = ls1 * dx
             ops.gemm(w.dy, b.t.wproj, w.do)
             dqkv, dt = w.dqkv_all[l], w.dt_all[l]
-            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, dqkv, B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[l] if self.attn_residual else None)
+            ops.attention_bwd(w.qkv[l], w.o[l], w.do, w.lse[l], w.dsum, dqkv, B, c.ntok, c.H, c.Dh, scale, out_res=w.ores[l] if w.ores_on else None)
             dq, dv = dqkv, dqkv.view(-1)[2 * D:]
             # dt_q = dq @ (a B_q)^T, dt_v = dv @ (a B_v)^T: one launch
             ops.skinny_xw2(dq, pk.Bq16[l], dt, dv, pk.Bv16[l], dt.view(-1)[r_:], ldx=3 * D, ldw=D, ldo=2 * r_, M=M, K=D, R=r_)
