@@ -356,8 +356,10 @@ def main(argv=None):
     if rank == 0:
         if probe["n"]:
             ach = probe["flops"] / (probe["ms"] * 1e-3)
-            traffic, src = pmc_traffic()
-            res["roofline"] = {"bound": "mfma", "kernel": "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE> (8 waves)",
+            dom = ("mvit_gemm::ws::gemm_ws_kernel<STORE> (256x128 tile, 8 MFMA + 4 DMA waves)" if ops.PROBE.ws else
+                   "mvit_gemm::gemm_kernel<256,128,4,2,DENSE,STORE> (8 waves)")
+            traffic, src = pmc_traffic("gemm_ws_kernel<0>" if ops.PROBE.ws else "gemm_kernel<256, 128, 4, 2, 0, 0>")
+            res["roofline"] = {"bound": "mfma", "kernel": dom,
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16, 4), "traffic": traffic, "traffic_source": src,
                                "launches": probe["n"], "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2),
@@ -402,6 +404,8 @@ def _pmc_key(kprobe_name):
     """name of a KPROBE entry as rocprofv3 spells the kernel: 'mvit_gemm::gemm_kernel<256,128,4,2,DENSE,RESID>' ->
     'gemm_kernel<256, 128, 4, 2, 0, 3>'; the attention entries are spelled as KPROBE spells them (backward = sum of its launches)"""
     epi = {"STORE": 0, "GELU": 1, "SWIGLU": 2, "RESID": 3, "PATCH": 4, "STATS": 5, "DSWIGLU": 6, "DGELU": 7}
+    if "gemm_ws_kernel<" in kprobe_name:
+        return "ws::gemm_ws_kernel<%d>" % epi.get(kprobe_name.split("<", 1)[1].rstrip(">"), -1)
     if "gemm_kernel<" in kprobe_name:
         f = kprobe_name.split("<", 1)[1].rstrip(">").split(",")
         return "gemm_kernel<%s, %s, %s, %s, 0, %d>" % (f[0], f[1], f[2], f[3], epi.get(f[5], -1))
@@ -429,7 +433,7 @@ def pmc_traffic_all():
 PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
-def pmc_traffic():
+def pmc_traffic(kernel="gemm_kernel<256, 128, 4, 2, 0, 0>"):
     """(HBM-side bytes per launch of the dominant kernel, where the figure comes from).  The PMC counters cannot be read from
     inside the timed run: the value is the committed rocprofv3 summary of this same command (separate FETCH_SIZE / WRITE_SIZE
     passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of MI355X_MICROARCH.md; L2-side fabric requests, so
@@ -439,7 +443,7 @@ def pmc_traffic():
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 k = json.load(f)["kernels"]
             for kn, v in k.items():
-                if "gemm_kernel<256, 128, 4, 2, 0, 0>" in kn:
+                if kernel in kn:
                     return round(v["hbm_bytes_per_launch_corrected"]), f"profiles/{name} (static: committed rocprofv3 --pmc passes)"
         except Exception:  # noqa: BLE001
             continue

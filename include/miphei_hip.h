@@ -72,7 +72,8 @@ typedef struct mvit_gemm_args {
 } mvit_gemm_args;
 
 MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream);
-/* which tile variant mvit_gemm_bf16 runs for this problem: (BM << 20) | (BN << 8) | (WAVES_M << 4) | WAVES_N
+/* which tile variant mvit_gemm_bf16 runs for this problem: (BM << 20) | (BN << 8) | (WAVES_M << 4) | WAVES_N, with bit 30 set when
+ * the wave-specialised kernel (csrc/gemm_ws.hip) takes it
  * (measurement only: bench.py attributes its HIP-event timings to one kernel instantiation with it) */
 MVIT_API int mvit_gemm_variant(const mvit_gemm_args* args);
 

@@ -39,7 +39,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// sigmoid on the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: `1.f / x` compiles to v_div_scale x 2 + v_rcp +
+// 4 v_fma + v_div_fmas + v_div_fixup -- ten VALU instructions per element in epilogues whose run time is VALU issue (round 4:
+// the d(SwiGLU) epilogue issued 3.4 VALU per MFMA over the whole kernel, profiles/r04_gemm_sq_counters_baseline.txt)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));

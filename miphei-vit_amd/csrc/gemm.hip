@@ -6,6 +6,8 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s);
 
 namespace mvit_gemm {
 int gemm_num_cus() { return mvit_num_cus(); }
+bool ws_supported(const mvit_gemm_args& a);           // gemm_ws.hip: the wave-specialised 256x128 kernel (round 4)
+int launch_ws(const mvit_gemm_args& a, hipStream_t s);
 }  // namespace mvit_gemm
 
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
@@ -81,9 +83,23 @@ static int select_variant(const mvit_gemm_args& a) {
   return id(128, 32, 4, 1);
 }
 
+static bool takes_ws(const mvit_gemm_args& a, int v) {
+  // Wave-specialised kernel (gemm_ws.hip: producer waves own the operand DMA, consumer waves never wait on the vector-memory counter):
+  // takes the dense problems of the 8-wave 256-row tiles it supports.  MVIT_GEMM_WS = bit mask over epilogues (1 store, 2 SwiGLU,
+  // 4 residual, 8 d(SwiGLU)); which kernel runs depends only on the problem.
+  MVIT_KNOB(ws_mask, "MVIT_GEMM_WS", 15);
+  auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
+  if (a.amode != MVIT_A_DENSE || (v != id(256, 128, 4, 2) && v != id(256, 256, 2, 4)) || !mvit_gemm::ws_supported(a)) return false;
+  const int bit = a.epi == MVIT_EPI_STORE ? 1 : a.epi == MVIT_EPI_SWIGLU ? 2 : a.epi == MVIT_EPI_RESID ? 4 : 8;
+  return (ws_mask & bit) != 0;
+}
+
 extern "C" MVIT_API int mvit_gemm_variant(const mvit_gemm_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return MVIT_EINVAL;
-  return select_variant(*args);
+  const int v = select_variant(*args);
+  if (v < 0) return v;
+  // bit 30: the wave-specialised kernel runs this problem (its tile is 256x128, 8 MFMA waves as 4 x 2, plus 4 DMA waves)
+  return takes_ws(*args, v) ? (((256 << 20) | (128 << 8) | (4 << 4) | 2) | (1 << 30)) : v;
 }
 
 static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
@@ -92,6 +108,7 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
   const int v = select_variant(a);
   if (v < 0) return MVIT_EINVAL;
+  if (takes_ws(a, v)) return launch_ws(a, s);
   if (v == id(256, 256, 2, 2)) return launch_dense<256, 256, 2, 2>(a, s);
   if (v == id(256, 256, 2, 4)) return launch_dense<256, 256, 2, 4>(a, s);
   if (v == id(256, 128, 2, 2)) return launch_dense<256, 128, 2, 2>(a, s);

@@ -1,0 +1,446 @@
+// Wave-specialised bf16 MFMA GEMM for gfx950 (round 4): C[M,N] = A[M,K] * B[N,K]^T (+ A2 * B2^T), 256x128x64 tiles.
+//
+// Why a second dense kernel.  In gemm_kernel.hpp every wave of a block is loader, MFMA issuer and store issuer at once, and the three
+// roles meet in ONE per-wave counter: `s_waitcnt vmcnt` counts the operand DMA (buffer_load ... lds) and the epilogue's global stores
+// alike (gfx9 has no separate store counter, and loads / stores complete out of order with respect to each other, so hipcc waits for
+// zero whenever both kinds are pending).  Consequences measured in rounds 1-3: (i) the next tile's first K step cannot start before the
+// previous tile's stores have drained (fc1 + SwiGLU 139 vs 123 us bare, dfc2 + d(SwiGLU) 96 vs 64 us, proj / fc2 + residual 50 vs
+// 42 us: ~2.6 ms of a 36.5 ms step with the MFMA pipe idle); (ii) each of the 6 DMA pieces a wave issues per K tile costs that wave
+// ~100 issue cycles in the middle of its MFMA stream.
+// Here the roles are split over the waves of a 768-thread block:
+//   * waves 0-7  (consumers): 64x64 sub-tiles on v_mfma_f32_16x16x32_bf16, fragments double-buffered in registers, NO vector-memory
+//     instruction in the K loop and no vmcnt wait anywhere on the way from one tile's epilogue into the next tile's K loop: their
+//     stores drain while the next tile computes;
+//   * waves 8-11 (producers): issue all operand DMA (12 pieces of 1 KiB per K tile each), wait for it with counted vmcnt and publish a
+//     landed K tile through the block barrier the K step already has.  They run two K tiles ahead, across tile boundaries.
+// One s_barrier per K tile (all 12 waves), one more per output tile (the epilogue panel lives in the LDS stage consumed last).
+// Three waves per SIMD -> at most 168 VGPRs per lane (MI355X_MICROARCH.md, register table).
+//
+// LDS image of a stage, fragment addressing, the XOR swizzle on the DMA source address and the tile order are those of
+// gemm_kernel.hpp (so are the epilogue formulas: STORE / SWIGLU / RESID / DSWIGLU, vector paths only; everything else -- unaligned
+// operands, N % 128, K % 64, split-K, convolution gathers -- stays on gemm_kernel.hpp, see mvit_gemm::ws_supported).
+#include <type_traits>
+#include "common.hpp"
+#include "../../include/miphei_hip.h"
+
+namespace mvit_gemm {
+int gemm_num_cus();
+
+namespace ws {
+constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
+constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+constexpr int NCW = 8, NPW = 4;                      // consumer / producer waves
+constexpr int PPW = (BM + BN) / 8 / NPW;             // DMA pieces (8 rows x 128 B) per producer wave per K tile = 12
+constexpr int PA = BM / 8 / NPW, PB = BN / 8 / NPW;  // of which A / B pieces: 8 + 4
+constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4;
+constexpr int SLD = WTN + 4, SLAB = 16 * SLD;        // wave-private epilogue panel: 16 rows x 68 floats
+constexpr int V = 8;
+constexpr unsigned OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+static_assert(PPW == PA + PB, "piece split");
+static_assert((size_t)NCW * SLAB * 4 <= (size_t)BUF_BYTES, "epilogue panels must fit one stage");
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long long v = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+struct TileOrder {   // virtual tile id -> XCD-aware, grouped (8 tile rows x all columns) coordinates, as gemm_kernel.hpp
+  int tiles_m, tiles_n, ntiles;
+  __device__ __forceinline__ void get(int vt, int& m0, int& n0) const {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = vt & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (wg / per_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    m0 = (first_m + (wg % per_group) % gsz) * BM;
+    n0 = ((wg % per_group) / gsz) * BN;
+  }
+};
+
+template <int EPI>
+__global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_gemm_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  TileOrder ord;
+  ord.tiles_m = (p.M + BM - 1) / BM;
+  ord.tiles_n = p.N / BN;
+  ord.ntiles = ord.tiles_m * ord.tiles_n;
+  const int nk1 = p.K / BK;
+  const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
+  const int nk = nk1 + nk2;
+  const int my_tiles = ((int)blockIdx.x < ord.ntiles) ? (ord.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int G = my_tiles * nk;   // K tiles this block walks (global step index g = tile * nk + k)
+
+  if (wave >= NCW) {
+    // ================================================================ producers
+    const int pw = wave - NCW;
+    // per-lane source offsets of this wave's pieces (tile independent: the tile enters through the descriptor's base; the K advance
+    // rides on the scalar offset, which is outside the range check -- every row is a whole multiple of 128 B wide here)
+    unsigned voA[PA], voB[PB], voA2[PA], voB2[PB];
+    const int rl = lane >> 3, c8 = lane & 7;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int row = (pw * PA + j) * 8 + rl;
+      const int cs = c8 ^ ((row >> 1) & 7);
+      voA[j] = (unsigned)row * (unsigned)p.lda * 2u + (unsigned)cs * 16u;
+      voA2[j] = (cs * 8 < p.K2) ? (unsigned)row * (unsigned)p.lda2 * 2u + (unsigned)cs * 16u : OOB;   // (K2 < 64: the valid chunks)
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int row = (pw * PB + j) * 8 + rl;
+      const int cs = c8 ^ ((row >> 1) & 7);
+      voB[j] = (unsigned)row * (unsigned)p.ldb * 2u + (unsigned)cs * 16u;
+      voB2[j] = (cs * 8 < p.K2) ? (unsigned)row * (unsigned)p.ldb2 * 2u + (unsigned)cs * 16u : OOB;
+    }
+    __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2;
+    auto set_tile = [&](int vt) __attribute__((always_inline)) {
+      int m0, n0;
+      ord.get(vt, m0, n0);
+      const unsigned vm = (unsigned)min(BM, p.M - m0), vn = (unsigned)min(BN, p.N - n0);
+      // num_records = the valid rows of this tile: rows beyond M / N read as zero (hardware range check on the vector offset)
+      rsA = make_rsrc((const bf16_t*)p.A + (size_t)m0 * p.lda, vm * (unsigned)p.lda * 2u);
+      rsB = make_rsrc((const bf16_t*)p.B + (size_t)n0 * p.ldb, vn * (unsigned)p.ldb * 2u);
+      rsA2 = make_rsrc(p.A2 ? (const bf16_t*)p.A2 + (size_t)m0 * p.lda2 : (const bf16_t*)p.A, p.A2 ? vm * (unsigned)p.lda2 * 2u : 0u);
+      rsB2 = make_rsrc(p.B2 ? (const bf16_t*)p.B2 + (size_t)n0 * p.ldb2 : (const bf16_t*)p.B, p.B2 ? vn * (unsigned)p.ldb2 * 2u : 0u);
+    };
+    // (generic lambda: the DMA builtin exists for the device target only, see gemm_kernel.hpp)
+    auto issue = [&](int k, int stage, auto) __attribute__((always_inline)) {
+      char* a = smem + stage * BUF_BYTES + pw * PA * 1024;
+      char* b = smem + stage * BUF_BYTES + A_BYTES + pw * PB * 1024;
+      if (k < nk1) {
+        const int soff = k * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 1024), 16, voA[j], soff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * 1024), 16, voB[j], soff, 0, 0);
+      } else {
+        // second K range (LoRA: A2 = t [M, 2r], B2 = [N, 2r]); chunks at or beyond K2 are zero (OOB offsets above, first K tile of
+        // the range only: K2 <= 64 is what the dispatcher admits)
+#pragma unroll
+        for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 1024), 16, voA2[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * 1024), 16, voB2[j], 0, 0, 0);
+      }
+    };
+    // look-ahead cursor: the next K tile to request
+    int l_vt = blockIdx.x, l_k = 0, l_stage = 0, l_g = 0;
+    if (G > 0) set_tile(l_vt);
+    auto issue_next = [&](auto tag) __attribute__((always_inline)) {
+      issue(l_k, l_stage, tag);
+      ++l_g;
+      l_stage = l_stage + 1 == NSTAGE ? 0 : l_stage + 1;
+      if (++l_k == nk) {
+        l_k = 0;
+        l_vt += gridDim.x;
+        if (l_g < G) set_tile(l_vt);
+      }
+    };
+    if (G > 0) issue_next(0);
+    if (G > 1) {
+      issue_next(0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                        // B(-1): K tile 0 has landed
+    int g = 0;
+    for (int t = 0; t < my_tiles; ++t) {
+      for (int k = 0; k < nk; ++k, ++g) {
+        // stage (g + 2) % 3 = the one consumed in step g - 1: free since the barrier that ended it
+        if (g + 2 < G) {
+          issue_next(0);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // everything but the request just made: K tile g + 1 is in LDS
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                    // B(g)
+      }
+      __builtin_amdgcn_s_barrier();                      // B'(tile): the consumers are done with the epilogue panel (= stage of step g - 1)
+    }
+    return;
+  }
+
+  // ================================================================== consumers
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int fr = lane & 15, fh = lane >> 4;            // fragment row, 16-byte K chunk inside a 32-wide sub-step
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const unsigned sw = (unsigned)(((s * 4 + fh) ^ ((fr >> 1) & 7)) << 4);
+    aoff[s] = (unsigned)(wave_m * WTM + fr) * 128u + sw;
+    boff[s] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + fr) * 128u + sw;
+  }
+  const bool out_f32 = p.flags & MVIT_OUT_F32;
+  float* Cf = (float*)p.C;
+  bf16_t* Cb = (bf16_t*)p.C;
+  constexpr int CPR = (EPI == MVIT_EPI_SWIGLU) ? 32 / V : WTN / V;   // lanes per output row
+  constexpr int RPP = 64 / CPR;                                      // rows per pass: 8 (16 for SwiGLU)
+  constexpr int NPASS = 16 / RPP;
+  const int lc = (lane % CPR) * V, lr = lane / CPR;
+
+  __builtin_amdgcn_s_barrier();                          // B(-1)
+  int stage = 0;
+  int vt = blockIdx.x;
+  for (int t = 0; t < my_tiles; ++t, vt += gridDim.x) {
+    int m0, n0;
+    ord.get(vt, m0, n0);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][TM], fb[2][TN];
+    {
+      const char* cur = smem + stage * BUF_BYTES;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[0][i] = *(const bf16x8*)(cur + aoff[0] + i * 2048);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = *(const bf16x8*)(cur + boff[0] + j * 2048);
+    }
+    // One K tile: sub-step 0 (16 MFMAs) carries the eight fragment reads of sub-step 1, one behind every other MFMA, in the order
+    // sub-step 1 consumes them (a0, b0..b3, a1..a3); sub-step 1 runs six MFMAs, hands the stage over (its reads are back: lgkmcnt(0),
+    // block barrier = the next K tile has landed, see the producers) and carries the first fragments of the next stage on the rest.
+    auto read_sub = [&](const char* base, int s, int r, bf16x8 (&xa)[TM], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+      if (r == 0)
+        xa[0] = *(const bf16x8*)(base + aoff[s]);
+      else if (r <= TN)
+        xb[r - 1] = *(const bf16x8*)(base + boff[s] + (r - 1) * 2048);
+      else
+        xa[r - TN] = *(const bf16x8*)(base + aoff[s] + (r - TN) * 2048);
+    };
+    auto kstep = [&](auto more_tag) __attribute__((always_inline)) {
+      constexpr bool more = decltype(more_tag)::value;   // another K tile of THIS output tile follows
+      const char* cur = smem + stage * BUF_BYTES;
+#pragma unroll
+      for (int m = 0; m < TM * TN; ++m) {
+        const int i = m / TN, j = m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        if ((m & 1) == 0) read_sub(cur, 1, m >> 1, fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr int HO = 6;
+#pragma unroll
+      for (int m = 0; m < HO; ++m) {
+        const int i = m / TN, j = m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // B(g)
+      __builtin_amdgcn_sched_barrier(0);
+      stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+      const char* nxt = smem + stage * BUF_BYTES;
+#pragma unroll
+      for (int m = HO; m < TM * TN; ++m) {
+        const int i = m / TN, j = m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        if (more && m - HO < TM + TN) read_sub(nxt, 0, m - HO, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int k = 0; k + 1 < nk; ++k) kstep(std::true_type{});
+    kstep(std::false_type{});
+    // `stage` now names the first K tile of the NEXT output tile; the stage consumed last (every consumer is past its reads: the
+    // barrier inside the last step) holds the epilogue panels until B'
+    const int last = stage == 0 ? NSTAGE - 1 : stage - 1;
+    float* stg = (float*)(smem + last * BUF_BYTES) + (size_t)wave * SLAB;
+
+    // ---------------------------------------------------------------- epilogue (vector paths only: N % 128 == 0, aligned operands)
+    const int colw = n0 + wave_n * WTN;
+    const int col = colw + lc;
+    float bias[V], bias2[V], gam[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) bias[e] = bias2[e] = 0.f, gam[e] = 1.f;
+    if (p.bias) {
+      const float4 t0 = *(const float4*)(p.bias + col), t1 = *(const float4*)(p.bias + col + 4);
+      bias[0] = t0.x, bias[1] = t0.y, bias[2] = t0.z, bias[3] = t0.w, bias[4] = t1.x, bias[5] = t1.y, bias[6] = t1.z, bias[7] = t1.w;
+      if constexpr (EPI == MVIT_EPI_SWIGLU) {
+        const float4 u0 = *(const float4*)(p.bias + col + 32), u1 = *(const float4*)(p.bias + col + 36);
+        bias2[0] = u0.x, bias2[1] = u0.y, bias2[2] = u0.z, bias2[3] = u0.w, bias2[4] = u1.x, bias2[5] = u1.y, bias2[6] = u1.z, bias2[7] = u1.w;
+      }
+    }
+    if (EPI == MVIT_EPI_RESID && p.gamma) {
+      const float4 t0 = *(const float4*)(p.gamma + col), t1 = *(const float4*)(p.gamma + col + 4);
+      gam[0] = t0.x, gam[1] = t0.y, gam[2] = t0.z, gam[3] = t0.w, gam[4] = t1.x, gam[5] = t1.y, gam[6] = t1.z, gam[7] = t1.w;
+    }
+    constexpr bool AUX = (EPI == MVIT_EPI_RESID || EPI == MVIT_EPI_DSWIGLU);
+    // per-element operands of the whole sub-tile (residual stream / saved pre-activation) are requested up front: the fragment
+    // registers are dead here, and a load requested behind a store would wait for that store too (one counter, see the header)
+    uint4 pre[TM][NPASS][2];
+    float rsc_[TM][NPASS];                               // DropPath factor of each row's sample (residual epilogue; 1 without rowscale)
+    if constexpr (EPI == MVIT_EPI_RESID) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < NPASS; ++it) {
+          const int row = m0 + wave_m * WTM + i * 16 + it * RPP + lr;
+          rsc_[i][it] = p.rowscale ? p.rowscale[row < p.M ? row : p.M - 1] : 1.f;
+        }
+    }
+    if constexpr (AUX) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < NPASS; ++it) {
+          const int row = m0 + wave_m * WTM + i * 16 + it * RPP + lr;
+          const int rr = row < p.M ? row : p.M - 1;      // (clamped: an unconditional load, results of rows >= M are not stored)
+          if constexpr (EPI == MVIT_EPI_RESID) {
+            const float* rp = p.aux ? (const float*)p.aux + (size_t)rr * p.ldaux + col : Cf + (size_t)rr * p.ldc + col;
+            pre[i][it][0] = ((const uint4*)rp)[0];
+            pre[i][it][1] = ((const uint4*)rp)[1];
+          } else {
+            const bf16_t* u = (const bf16_t*)p.aux + (size_t)rr * p.ldaux + (((col >> 5) << 6) + (col & 31));
+            pre[i][it][0] = *(const uint4*)u;
+            pre[i][it][1] = *(const uint4*)(u + 32);
+          }
+        }
+    }
+    auto panel8 = [&](int rl_, int c0, float (&o)[V]) __attribute__((always_inline)) {
+      const float4 t0 = *(const float4*)(stg + rl_ * SLD + c0), t1 = *(const float4*)(stg + rl_ * SLD + c0 + 4);
+      o[0] = t0.x, o[1] = t0.y, o[2] = t0.z, o[3] = t0.w, o[4] = t1.x, o[5] = t1.y, o[6] = t1.z, o[7] = t1.w;
+    };
+    auto un8bf = [&](const uint4& tq, float (&o)[V]) __attribute__((always_inline)) {
+      const uint32_t u[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+    };
+    auto pk8 = [&](const float (&o)[V]) __attribute__((always_inline)) {
+      return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      // park rows 16 i .. 16 i + 15 of the sub-tile (C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + register)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) stg[(r4 + 4 * fh) * SLD + j * 16 + fr] = acc[i][j][r4];
+      // ONE wait for every load of this epilogue (column constants, per-element operands), in front of the first store: from here
+      // on only stores are pending, and nothing below waits for them (s_waitcnt through the builtin, so that hipcc's own counter
+      // bookkeeping sees it: with the loads under `if (p.bias)` it otherwise re-waits -- for zero, stores included -- at every use)
+      if (i == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#pragma unroll
+      for (int it = 0; it < NPASS; ++it) {
+        const int rl_ = it * RPP + lr;
+        const int row = m0 + wave_m * WTM + i * 16 + rl_;
+        const bool rok = row < p.M;
+        if constexpr (EPI == MVIT_EPI_SWIGLU) {
+          float a_[V], b_[V], g_[V];
+          panel8(rl_, lc, a_);
+          panel8(rl_, lc + 32, b_);
+#pragma unroll
+          for (int e = 0; e < V; ++e) a_[e] += bias[e], b_[e] += bias2[e];
+#pragma unroll
+          for (int e = 0; e < V; ++e) g_[e] = a_[e] * sigmoidf_(a_[e]) * b_[e];
+          if (rok) {
+            if (p.aux) {
+              bf16_t* aux = (bf16_t*)p.aux + (size_t)row * p.ldaux + col;
+              *(uint4*)aux = pk8(a_);
+              *(uint4*)(aux + 32) = pk8(b_);
+            }
+            *(uint4*)(Cb + (size_t)row * p.ldc + ((colw >> 1) + lc)) = pk8(g_);
+          }
+        } else {
+          float v[V];
+          panel8(rl_, lc, v);
+#pragma unroll
+          for (int e = 0; e < V; ++e) v[e] += bias[e];
+          if constexpr (EPI == MVIT_EPI_STORE) {
+            const size_t o = (size_t)row * p.ldc + col;
+            if (rok) {
+              if (out_f32) {
+                ((float4*)(Cf + o))[0] = make_float4(v[0], v[1], v[2], v[3]);
+                ((float4*)(Cf + o))[1] = make_float4(v[4], v[5], v[6], v[7]);
+              } else {
+                if (p.flags & MVIT_ACCUM_BF16) {
+                  float old[V];
+                  un8bf(*(const uint4*)(Cb + o), old);
+#pragma unroll
+                  for (int e = 0; e < V; ++e) v[e] += old[e];
+                }
+                *(uint4*)(Cb + o) = pk8(v);
+              }
+            }
+          } else if constexpr (EPI == MVIT_EPI_RESID) {
+            const uint4 t0 = pre[i][it][0], t1 = pre[i][it][1];
+            float r_[V] = {__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w),
+                           __uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w)};
+            const float rsc = rsc_[i][it];
+#pragma unroll
+            for (int e = 0; e < V; ++e) r_[e] += rsc * gam[e] * v[e];
+            if (rok) {
+              float* dst = Cf + (size_t)row * p.ldc + col;
+              ((float4*)dst)[0] = make_float4(r_[0], r_[1], r_[2], r_[3]);
+              ((float4*)dst)[1] = make_float4(r_[4], r_[5], r_[6], r_[7]);
+            }
+          } else if constexpr (EPI == MVIT_EPI_DSWIGLU) {
+            // gate columns col..col+7 live at packed positions ca.. (a) and ca+32.. (b) of the saved pre-activation
+            const int ca = ((col >> 5) << 6) + (col & 31);
+            float a_[V], b_[V], da[V], db[V];
+            un8bf(pre[i][it][0], a_);
+            un8bf(pre[i][it][1], b_);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const float sg = sigmoidf_(a_[e]);
+              const float vs = v[e] * sg;
+              da[e] = vs * b_[e] * (1.f + a_[e] * (1.f - sg));
+              db[e] = vs * a_[e];
+            }
+            if (rok) {
+              bf16_t* dst = Cb + (size_t)row * p.ldc + ca;
+              *(uint4*)dst = pk8(da);
+              *(uint4*)(dst + 32) = pk8(db);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();                        // B'(tile): the panel stage may be refilled
+  }
+}
+
+}  // namespace ws
+
+// problems the wave-specialised kernel takes (everything else stays on gemm_kernel.hpp)
+bool ws_supported(const mvit_gemm_args& a) {
+  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800))) return false;
+  if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_SWIGLU && a.epi != MVIT_EPI_RESID && a.epi != MVIT_EPI_DSWIGLU) return false;
+  if (a.M < 1024 || (a.N % 128) || (a.K % 64) || a.K < 64) return false;
+  if (a.A2 && (a.K2 > 64 || a.K2 <= 0)) return false;
+  if (a.epi == MVIT_EPI_RESID && !(a.flags & MVIT_OUT_F32)) return false;
+  if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_RESID && (a.flags & MVIT_OUT_F32)) return false;
+  if (a.epi != MVIT_EPI_STORE && (a.flags & MVIT_ACCUM_BF16)) return false;
+  // 32-bit byte offsets inside a tile's descriptor range
+  const long long maxld = a.lda > a.ldb ? a.lda : a.ldb;
+  if (256ll * maxld * 2 >= 0x7fffffffll) return false;
+  return true;
+}
+
+template <int EPI>
+static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
+  const int tiles = ((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN);
+  const size_t lds = (size_t)ws::NSTAGE * ws::BUF_BYTES;
+  int gx = gemm_num_cus();
+  if (gx > tiles) gx = tiles;
+  auto kern = ws::gemm_ws_kernel<EPI>;
+  static mvit_per_device_size raised;
+  if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return MVIT_EINVAL;
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(64 * (ws::NCW + ws::NPW)), lds, s, a);
+  return MVIT_LAUNCH_CHECK();
+}
+
+int launch_ws(const mvit_gemm_args& a, hipStream_t s) {
+  switch (a.epi) {
+    case MVIT_EPI_STORE: return launch_ws_one<MVIT_EPI_STORE>(a, s);
+    case MVIT_EPI_SWIGLU: return launch_ws_one<MVIT_EPI_SWIGLU>(a, s);
+    case MVIT_EPI_RESID: return launch_ws_one<MVIT_EPI_RESID>(a, s);
+    case MVIT_EPI_DSWIGLU: return launch_ws_one<MVIT_EPI_DSWIGLU>(a, s);
+    default: return MVIT_EINVAL;
+  }
+}
+
+}  // namespace mvit_gemm

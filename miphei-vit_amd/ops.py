@@ -26,6 +26,7 @@ class _Probe:
     def __init__(self):
         self.on = False
         self.events = []
+        self.ws = False        # the sampled launches ran the wave-specialised kernel
 
     def start(self):
         self.on, self.events = True, []
@@ -67,7 +68,8 @@ PROBE = _Probe()
 KPROBE = _KernelProbe()
 EPI_NAMES = {EPI_STORE: "STORE", EPI_GELU: "GELU", EPI_SWIGLU: "SWIGLU", EPI_RESID: "RESID", EPI_PATCH: "PATCH", EPI_STATS: "STATS",
              EPI_DSWIGLU: "DSWIGLU", EPI_DGELU: "DGELU"}
-PROBE_VARIANT = (256 << 20) | (128 << 8) | (4 << 4) | 2   # gemm_kernel<256,128,4,2,...>: largest share of the step
+PROBE_VARIANT = (256 << 20) | (128 << 8) | (4 << 4) | 2   # the 256x128 tile on 8 MFMA waves (4 x 2): largest share of the step
+WS_BIT = 1 << 30                                         # mvit_gemm_variant: the wave-specialised kernel (gemm_ws.hip) runs the problem
 
 
 def _stream():
@@ -130,7 +132,7 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     # bench.py's roofline leg: HIP events around the launches that run the dominant instantiation
     # (gemm_kernel<256,128,4,2,DENSE,STORE>: the dgrad GEMMs and the plain-store forward ones), as reported by the library's own dispatcher
     probe = (PROBE.on and amode == A_DENSE and epi == EPI_STORE and ksplit == 1
-             and L.lib().mvit_gemm_variant(C.byref(g)) == PROBE_VARIANT)
+             and (L.lib().mvit_gemm_variant(C.byref(g)) & ~WS_BIT) == PROBE_VARIANT)
     kprobe = KPROBE.on and amode == A_DENSE and ksplit == 1
     if probe or kprobe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -139,11 +141,13 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     if probe or kprobe:
         e1.record()
         if probe:
+            PROBE.ws = bool(L.lib().mvit_gemm_variant(C.byref(g)) & WS_BIT)
             PROBE.events.append((e0, e1, 2.0 * g.M * g.N * (g.K + g.K2)))
         if kprobe:
             v = L.lib().mvit_gemm_variant(C.byref(g))
-            KPROBE.add(f"mvit_gemm::gemm_kernel<{v >> 20},{(v >> 8) & 0xfff},{(v >> 4) & 15},{v & 15},DENSE,{EPI_NAMES.get(epi, epi)}>",
-                       e0, e1, 2.0 * g.M * g.N * (g.K + g.K2))
+            name = (f"mvit_gemm::ws::gemm_ws_kernel<{EPI_NAMES.get(epi, epi)}>" if v & WS_BIT else
+                    f"mvit_gemm::gemm_kernel<{v >> 20},{(v >> 8) & 0xfff},{(v >> 4) & 15},{v & 15},DENSE,{EPI_NAMES.get(epi, epi)}>")
+            KPROBE.add(name, e0, e1, 2.0 * g.M * g.N * (g.K + g.K2))
     return c
 
 

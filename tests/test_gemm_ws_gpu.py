@@ -1,0 +1,110 @@
+"""GPU: the wave-specialised 256x128 GEMM (csrc/gemm_ws.hip: producer waves own the operand DMA, consumer waves run MFMA + epilogue)
+against plain PyTorch fp32 math -- every epilogue it takes over (store, SwiGLU, LayerScale + residual, d(SwiGLU)), ragged M (last tile
+row partly empty), several tiles per persistent block, one and two K tiles, the LoRA second K range, C += and the DropPath row
+scale.  Replaces nn.Linear of the timm block (/root/reference/src/generators/foundation_models.py:53-57) and QkvWithLoRA
+(/root/reference/src/generators/lora.py:29-33) on the benchmark's shapes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _rnd(g, *s, dt=torch.bfloat16, scale=1.0):
+    return (torch.randn(*s, generator=g, device="cuda") * scale).to(dt)
+
+
+def _is_ws(M, N, K, epi=0, flags=0, K2=0):
+    import ctypes as C
+    import miphei_vit_amd._lib as L
+    g = L.GemmArgs()
+    g.M, g.N, g.K, g.K2, g.epi, g.flags, g.ksplit, g.amode = M, N, K, K2, epi, flags, 1, 0
+    return L.lib().mvit_gemm_variant(C.byref(g)) in ((256 << 20) | (128 << 8) | (4 << 4) | 2, (256 << 20) | (256 << 8) | (2 << 4) | 4)
+
+
+@pytest.mark.parametrize("M,N,K", [(5264, 1536, 1536), (5264, 4608, 64), (1024, 128, 128), (2303, 384, 4608), (5264, 4608, 1536),
+                                   (70000, 128, 192)])
+def test_ws_store(M, N, K):
+    import miphei_vit_amd.ops as ops
+    assert _is_ws(M, N, K)
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a, b, bias = _rnd(g, M, K), _rnd(g, N, K, scale=K ** -0.5), _rnd(g, N, dt=torch.float32)
+    ref = a.float() @ b.float().t() + bias
+    c = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, b, c, bias=bias)
+    assert _rel(c.float(), ref) < 4e-3
+    c32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm(a, b, c32, flags=ops.OUT_F32)
+    assert _rel(c32, ref - bias) < 1e-5 * K ** 0.5 + 2e-6
+    c0 = _rnd(g, M, N)
+    c2 = c0.clone()
+    ops.gemm(a, b, c2, flags=ops.ACCUM_BF16)
+    assert _rel(c2.float(), c0.float() + ref - bias) < 6e-3
+    # strided operands / output (leading dimensions larger than the extents)
+    abig, cbig = _rnd(g, M, K + 64), torch.zeros(M, N + 128, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(abig, b, cbig, M=M, K=K, lda=K + 64, ldc=N + 128)
+    assert _rel(cbig[:, :N].float(), abig[:, :K].float() @ b.float().t()) < 4e-3 and float(cbig[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,K2", [(5264, 4608, 1536, 16), (2100, 384, 1536, 16), (1300, 256, 192, 64), (5264, 1536, 64, 8)])
+def test_ws_second_k_range(M, N, K, K2):
+    import miphei_vit_amd.ops as ops
+    g = torch.Generator(device="cuda").manual_seed(K2 + M)
+    a, b = _rnd(g, M, K), _rnd(g, N, K, scale=K ** -0.5)
+    a2, b2 = _rnd(g, M, K2), _rnd(g, N, K2, scale=0.3)
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, b, c, a2=a2, b2=b2, K2=K2)
+    assert _rel(c.float(), a.float() @ b.float().t() + a2.float() @ b2.float().t()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(5264, 1536, 1536), (5264, 1536, 4096), (1100, 256, 64)])
+def test_ws_layerscale_residual(M, N, K):
+    import miphei_vit_amd.ops as ops
+    g = torch.Generator(device="cuda").manual_seed(3 * M + K)
+    a, b = _rnd(g, M, K), _rnd(g, N, K, scale=K ** -0.5)
+    bias, gam, res = _rnd(g, N, dt=torch.float32), _rnd(g, N, dt=torch.float32), _rnd(g, M, N, dt=torch.float32)
+    rs = (torch.rand(M, generator=g, device="cuda") < 0.8).float() / 0.8
+    lin = a.float() @ b.float().t() + bias
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm(a, b, out, bias=bias, gamma=gam, aux=res, epi=ops.EPI_RESID, flags=ops.OUT_F32)
+    assert _rel(out - res, gam * lin) < 1e-5 * K ** 0.5 + 2e-6
+    out2 = res.clone()                                                       # in place: C is also the residual input
+    ops.gemm(a, b, out2, bias=bias, gamma=gam, epi=ops.EPI_RESID, flags=ops.OUT_F32)
+    assert torch.equal(out2, out)
+    ops.gemm(a, b, out, bias=bias, gamma=gam, aux=res, epi=ops.EPI_RESID, flags=ops.OUT_F32, rowscale=rs)
+    assert _rel(out - res, rs[:, None] * gam * lin) < 1e-5 * K ** 0.5 + 2e-6
+
+
+@pytest.mark.parametrize("M,D,H", [(5264, 1536, 4096), (5264, 448, 2048), (1030, 64, 128)])
+def test_ws_swiglu_and_its_backward(M, D, H):
+    """fc1 with the packed [a32 | b32] column groups -> g = silu(a) * b (+ saved pre-activation), and the dgrad GEMM through fc2 with
+    the d(SwiGLU) epilogue (timm SwiGLUPacked)"""
+    import miphei_vit_amd.ops as ops
+    g = torch.Generator(device="cuda").manual_seed(M + H)
+    x, w1, b1 = _rnd(g, M, D), _rnd(g, 2 * H, D, scale=D ** -0.5), _rnd(g, 2 * H, dt=torch.float32, scale=0.1)
+    u = torch.empty(M, 2 * H, device="cuda", dtype=torch.bfloat16)
+    gate = torch.empty(M, H, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, w1, gate, bias=b1, aux=u, epi=ops.EPI_SWIGLU)
+    pre = (x.float() @ w1.float().t() + b1).view(M, H // 32, 2, 32)
+    a_ref, b_ref = pre[:, :, 0].reshape(M, H), pre[:, :, 1].reshape(M, H)
+    assert _rel(u.float(), pre.reshape(M, 2 * H)) < 4e-3
+    assert _rel(gate.float(), torch.nn.functional.silu(a_ref) * b_ref) < 6e-3
+    gate2 = torch.empty_like(gate)
+    ops.gemm(x, w1, gate2, bias=b1, epi=ops.EPI_SWIGLU)                       # without the saved pre-activation (inference)
+    assert torch.equal(gate2, gate)
+    # backward: dG = dY @ W2 (W2t [H, Dout] as the B operand), du = d(silu(a) b) * dG in the packed layout
+    Do = 256
+    dy, w2t = _rnd(g, M, Do), _rnd(g, H, Do, scale=Do ** -0.5)
+    du = torch.empty(M, 2 * H, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dy, w2t, du, aux=u, epi=ops.EPI_DSWIGLU)
+    uf = u.float().view(M, H // 32, 2, 32)
+    a_, b_ = uf[:, :, 0].reshape(M, H), uf[:, :, 1].reshape(M, H)
+    dG = dy.float() @ w2t.float().t()
+    sg = torch.sigmoid(a_)
+    da, db = dG * b_ * sg * (1 + a_ * (1 - sg)), dG * a_ * sg
+    ref = torch.stack([da.view(M, H // 32, 32), db.view(M, H // 32, 32)], dim=2).reshape(M, 2 * H)
+    assert _rel(du.float(), ref) < 6e-3
