@@ -172,6 +172,118 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
   }
 }
 
+// Round 4: the same arithmetic on a grid that fits the chip in ONE round.  ln_fwd_lora_kernel runs 16 rows per block with ~100 KB of LDS,
+// i.e. one block per CU: M = 5264 rows are 329 blocks = 1.29 rounds on 256 CUs, and a round of this kernel is one dependent chain
+// (row loads -> statistics -> stores -> barrier -> MFMA -> barrier -> store): 16.6 us in the training step at 3.0 TB/s where ln_fwd moves
+// its rows at 4.7.  Here a block owns a BALANCED share of the rows (ceil(M / blocks) <= 32: 21 at M = 5264 on 251 blocks), every wave
+// normalises up to TWO rows whose loads are all requested before the first use, the adapter matrix is staged once per block, and the
+// two 16-row groups share one pair of barriers: the product is 8 wave tasks (row group x K quarter) on waves 0-7.
+template <int NV, bool FULL = false>
+__global__ __launch_bounds__(1024) void ln_fwd_lora2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t,
+                                                            int M, int D, float eps, int R2, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const int RS = D * 2 + 16;                          // padded row image (bytes)
+  char* As = lds_raw;                                 // [16][RS]: AcatT rows (rows >= R2 zero)
+  char* Hs = lds_raw + 16 * RS;                       // [32][RS]: the block's normalised rows (two groups of 16)
+  float* part = (float*)(Hs + 32 * RS);               // [8][64][4] partial blocks (row group x K quarter)
+  const int nv = D >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r_begin = blockIdx.x * rows_per_block, r_end = min(M, r_begin + rows_per_block);
+  {
+    const int h16 = D >> 3;                           // 16-byte pieces per adapter row
+    for (int i = threadIdx.x; i < 16 * h16; i += 1024) {
+      const int j = i / h16, c = i - j * h16;
+      uint4 tq = ((const uint4*)AcatT)[(size_t)(j < R2 ? j : R2 - 1) * h16 + c];   // unconditional load, masked
+      const unsigned keep = j < R2 ? 0xffffffffu : 0u;
+      tq.x &= keep, tq.y &= keep, tq.z &= keep, tq.w &= keep;
+      *(uint4*)(As + j * RS + c * 16) = tq;
+    }
+  }
+  for (int base = r_begin; base < r_end; base += 32) {
+    const int rowA = base + wave, rowB = base + 16 + wave;
+    const bool okA = rowA < r_end, okB = rowB < r_end;
+    float4 va[NV], vb[NV];
+    {
+      const float4* xa = (const float4*)(x + (size_t)(okA ? rowA : r_end - 1) * D) + lane;   // + 64 * i: immediate offsets
+      const float4* xb = (const float4*)(x + (size_t)(okB ? rowB : r_end - 1) * D) + lane;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (FULL || lane + 64 * i < nv) va[i] = xa[64 * i];
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (FULL || lane + 64 * i < nv) vb[i] = xb[64 * i];
+    }
+    auto norm_row = [&](float4 (&v)[NV], int row, bool ok, int slot) __attribute__((always_inline)) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (FULL || lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      const float mu = wave_sum(s) / D;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (FULL || lane + 64 * i < nv) {
+          const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+          q += (a * a + bb * bb) + (c * c + d * d);
+        }
+      const float rs = rsqrtf(wave_sum(q) / D + eps);
+      uint2* o = (uint2*)(out + (size_t)row * D) + lane;
+      uint2* hl = (uint2*)(Hs + slot * RS) + lane;
+      const float4* wl = (const float4*)w + lane;
+      const float4* bl = (const float4*)b + lane;
+      uint2 r[NV];     // all results first, then all stores (see ln_fwd_kernel)
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (FULL || lane + 64 * i < nv) {
+          const float4 ww = wl[64 * i], bv = bl[64 * i];
+          r[i].x = pack2bf((v[i].x - mu) * rs * ww.x + bv.x, (v[i].y - mu) * rs * ww.y + bv.y);
+          r[i].y = pack2bf((v[i].z - mu) * rs * ww.z + bv.z, (v[i].w - mu) * rs * ww.w + bv.w);
+          hl[64 * i] = r[i];
+        }
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (FULL || lane + 64 * i < nv) o[64 * i] = r[i];
+      }
+    };
+    norm_row(va, rowA, okA, wave);
+    norm_row(vb, rowB, okB, 16 + wave);
+    __syncthreads();
+    // t blocks [16 tokens][16 columns] of the two row groups: K steps of 32, wave task = (group, K quarter) on waves 0-7
+    const int r16 = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 8) {
+      const int grp = wave >> 2, kw = wave & 3;
+      const char* ha = Hs + (grp * 16 + r16) * RS + kq * 16;
+      const char* ab = As + r16 * RS + kq * 16;
+      const int nks = D >> 5;
+      for (int ks = kw; ks < nks; ks += 4) {
+        const bf16x8 fa = *(const bf16x8*)(ha + ks * 64);
+        const bf16x8 fb = *(const bf16x8*)(ab + ks * 64);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[(wave * 64 + lane) * 4 + j] = acc[j];
+    }
+    __syncthreads();                      // the partial blocks are in LDS
+    // C/D layout of the 16x16 MFMA: col = lane & 15 (adapter column), row = (lane >> 4) * 4 + reg (token)
+    if ((wave == 0 || wave == 4) && r16 < R2) {
+      const int grp = wave >> 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int orow = base + grp * 16 + kq * 4 + j;
+        float val = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) val += part[((grp * 4 + k4) * 64 + lane) * 4 + j];   // fixed order: run-to-run identical
+        if (orow < r_end) t[(size_t)orow * R2 + r16] = f2bf(val);
+      }
+    }
+    if (base + 32 < r_end) __syncthreads();   // (more rows: the row images and partial blocks are rewritten)
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward (input grad only)
 // dx (+)= rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * w.  Statistics are recomputed from x.
 // Optionally emits dy = bf16(gamma_next * dx_total): the LayerScale-scaled gradient the next dgrad GEMM consumes.
@@ -403,6 +515,30 @@ MVIT_API int mvit_layernorm_lora_fwd(const float* x, const float* w, const float
                                      int M, int D, float eps, int R2, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (M <= 0 || D <= 0 || (D & 31) || D > 256 * LN_MAXV || R2 <= 0 || R2 > 16 || !AcatT || !t) return MVIT_EINVAL;
+  // two 16-row groups per block on a balanced grid (ln_fwd_lora2_kernel) where the 48 row images fit the LDS
+  const size_t lds2 = 48 * ((size_t)D * 2 + 16) + 8 * 64 * 4 * sizeof(float);
+#ifndef MVIT_LNL_TWO_GROUPS
+#define MVIT_LNL_TWO_GROUPS 1
+#endif
+  if (MVIT_LNL_TWO_GROUPS && lds2 <= 160 * 1024) {
+    int blocks = (M + 15) / 16;
+    if (blocks > mvit_num_cus()) blocks = mvit_num_cus();
+    const int rpb = (M + blocks - 1) / blocks;
+    blocks = (M + rpb - 1) / rpb;
+    auto launch2 = [&](auto kern, mvit_per_device_size& raised) {
+      if (mvit_ensure_dynamic_lds((const void*)kern, lds2, raised) != MVIT_OK) return (int)MVIT_EINVAL;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds2, (hipStream_t)stream, x, w, b, (bf16_t*)out, (const bf16_t*)AcatT,
+                         (bf16_t*)t, M, D, eps, R2, rpb);
+      return MVIT_LAUNCH_CHECK();
+    };
+    static mvit_per_device_size g2, g4, g6, h2, h4, h6;
+    if (D == 1536) return launch2(ln_fwd_lora2_kernel<6, true>, h6);
+    if (D == 1024) return launch2(ln_fwd_lora2_kernel<4, true>, h4);
+    if (D == 512) return launch2(ln_fwd_lora2_kernel<2, true>, h2);
+    if (D <= 512) return launch2(ln_fwd_lora2_kernel<2>, g2);
+    if (D <= 1024) return launch2(ln_fwd_lora2_kernel<4>, g4);
+    return launch2(ln_fwd_lora2_kernel<6>, g6);
+  }
   const size_t lds = (16 + LNL_ROWS) * ((size_t)D * 2 + 16) + 3 * 64 * 4 * sizeof(float);
   auto launch = [&](auto kern, mvit_per_device_size& raised) {
     if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return (int)MVIT_EINVAL;

@@ -27,7 +27,7 @@ def _is_ws(M, N, K, epi=0, flags=0, K2=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(5264, 1536, 1536), (5264, 4608, 64), (1024, 128, 128), (2303, 384, 4608), (5264, 4608, 1536),
-                                   (70000, 128, 192)])
+                                   (70000, 128, 192), (5264, 8192, 192)])      # the last one: ragged-M tail split (rows 5120.. on the small tiles)
 def test_ws_store(M, N, K):
     import miphei_vit_amd.ops as ops
     assert _is_ws(M, N, K)
@@ -61,7 +61,7 @@ def test_ws_second_k_range(M, N, K, K2):
     assert _rel(c.float(), a.float() @ b.float().t() + a2.float() @ b2.float().t()) < 4e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(5264, 1536, 1536), (5264, 1536, 4096), (1100, 256, 64)])
+@pytest.mark.parametrize("M,N,K", [(5264, 1536, 1536), (5264, 1536, 4096), (1100, 256, 64), (2600, 3200, 64)])   # last: tail split
 def test_ws_layerscale_residual(M, N, K):
     import miphei_vit_amd.ops as ops
     g = torch.Generator(device="cuda").manual_seed(3 * M + K)

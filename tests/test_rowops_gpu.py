@@ -105,7 +105,8 @@ def test_patch_prefix_cast():
     assert torch.equal(o, (xx * gam).bfloat16())
 
 
-@pytest.mark.parametrize("M,D,r", [(7, 64, 4), (329 * 2, 96, 8), (5264, 1536, 8), (1301, 1536, 4), (37, 512, 8), (21, 1024, 8), (19, 2048, 4), (23, 1280, 8)])
+@pytest.mark.parametrize("M,D,r", [(7, 64, 4), (329 * 2, 96, 8), (5264, 1536, 8), (1301, 1536, 4), (37, 512, 8), (21, 1024, 8), (19, 2048, 4), (23, 1280, 8),
+                                   (21056, 1536, 8), (8300, 512, 8), (530, 1536, 8)])   # more than 32 rows per block of the balanced grid; 33 blocks
 def test_layernorm_lora_fused_matches_ln_then_matmul(M, D, r):
     """LN1 + the LoRA down-projection in one pass: h identical to the plain LN kernel, t = bf16(h) @ bf16([A_q|A_v])."""
     ops = _ops()
