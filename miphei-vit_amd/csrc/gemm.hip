@@ -108,34 +108,10 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
   const int v = select_variant(a);
   if (v < 0) return MVIT_EINVAL;
-  if (takes_ws(a, v)) {
-    // Ragged M on the wave-specialised kernel: when the partly empty last tile row is what pushes the launch into another round of
-    // tiles (fc1 of the batch-16 step: 21 x 64 = 1344 tiles = 5.25 rounds on 256 CUs, but rows [0, 5120) are exactly 5), the whole
-    // rows go to the 256-row tiles and the remaining < 256 rows to a second launch on the small tiles: 144 x 8192 x 1536 there, a
-    // fraction of a tile time, instead of a sixth round with 192 CUs idle.  MVIT_GEMM_TAIL_SPLIT=0 switches it off (measurement).
-    MVIT_KNOB(tail_split, "MVIT_GEMM_TAIL_SPLIT", 1);
-    const int m_main = a.M / 256 * 256, m_tail = a.M - m_main;
-    if (tail_split && m_tail > 0 && m_main >= 1024) {
-      const long long cus = gemm_num_cus(), nt = a.N / 128;
-      const long long rounds_all = ((long long)(m_main / 256 + 1) * nt + cus - 1) / cus, rounds_main = ((long long)(m_main / 256) * nt + cus - 1) / cus;
-      if (rounds_main < rounds_all) {
-        mvit_gemm_args mn = a, tl = a;
-        mn.M = m_main;
-        tl.M = m_tail;
-        const size_t csz = (a.flags & MVIT_OUT_F32) ? 4 : 2;
-        const size_t auxsz = a.epi == MVIT_EPI_RESID ? 4 : 2;
-        tl.A = (const char*)a.A + (size_t)m_main * a.lda * 2;
-        tl.C = (char*)a.C + (size_t)m_main * a.ldc * csz;
-        if (a.A2) tl.A2 = (const char*)a.A2 + (size_t)m_main * a.lda2 * 2;
-        if (a.aux) tl.aux = (char*)a.aux + (size_t)m_main * a.ldaux * auxsz;
-        if (a.rowscale) tl.rowscale = a.rowscale + m_main;
-        const int rc = launch_ws(mn, s);
-        if (rc != MVIT_OK) return rc;
-        return dispatch(tl, s);       // (M < 1024: the 4-wave 128-row tiles of gemm_kernel.hpp)
-      }
-    }
-    return launch_ws(a, s);
-  }
+  // (Measured and dropped in round 4: a ragged-M split -- rows [0, 5120) of fc1 as exactly five rounds of 256-row tiles on this kernel,
+  // the remaining 144 rows as a second launch on the 128-row tiles -- 137.8 vs 133-135 us: the small launch costs what the sixth,
+  // three-quarters-empty round costs.)
+  if (takes_ws(a, v)) return launch_ws(a, s);
   if (v == id(256, 256, 2, 2)) return launch_dense<256, 256, 2, 2>(a, s);
   if (v == id(256, 256, 2, 4)) return launch_dense<256, 256, 2, 4>(a, s);
   if (v == id(256, 128, 2, 2)) return launch_dense<256, 128, 2, 2>(a, s);

@@ -36,6 +36,11 @@ constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4;
 constexpr int SLD = WTN + 4, SLAB = 16 * SLD;        // wave-private epilogue panel: 16 rows x 68 floats
 constexpr int V = 8;
 constexpr unsigned OOB = 0x80000000u;
+// measurement builds (make DEBUG_KNOBS=1 BUILD=build_aN LIB=../libmiphei_aN.so EXTRA=-DMVIT_WS_ABLATE=N; results are garbage):
+// bit 0 no operand DMA, bit 1 no MFMAs, bit 2 no fragment reads (tools/bench_ws_abl.py)
+#ifndef MVIT_WS_ABLATE
+#define MVIT_WS_ABLATE 0
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr;
 static_assert(PPW == PA + PB, "piece split");
 static_assert((size_t)NCW * SLAB * 4 <= (size_t)BUF_BYTES, "epilogue panels must fit one stage");
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     };
     // (generic lambda: the DMA builtin exists for the device target only, see gemm_kernel.hpp)
     auto issue = [&](int k, int stage, auto) __attribute__((always_inline)) {
+      if (MVIT_WS_ABLATE & 1) return;
       char* a = smem + stage * BUF_BYTES + pw * PA * 1024;
       char* b = smem + stage * BUF_BYTES + A_BYTES + pw * PB * 1024;
       if (k < nk1) {
@@ -219,15 +225,17 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 #pragma unroll
       for (int m = 0; m < TM * TN; ++m) {
         const int i = m / TN, j = m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
-        if ((m & 1) == 0) read_sub(cur, 1, m >> 1, fa[1], fb[1]);
+        if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        else asm volatile("" ::"v"(fa[0][i]), "v"(fb[0][j]));
+        if ((m & 1) == 0 && !(MVIT_WS_ABLATE & 4)) read_sub(cur, 1, m >> 1, fa[1], fb[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
       constexpr int HO = 6;
 #pragma unroll
       for (int m = 0; m < HO; ++m) {
         const int i = m / TN, j = m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        else asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][j]));
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -238,8 +246,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 #pragma unroll
       for (int m = HO; m < TM * TN; ++m) {
         const int i = m / TN, j = m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
-        if (more && m - HO < TM + TN) read_sub(nxt, 0, m - HO, fa[0], fb[0]);
+        if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        else asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][j]));
+        if (more && m - HO < TM + TN && !(MVIT_WS_ABLATE & 4)) read_sub(nxt, 0, m - HO, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
       }
     };

@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+if os.environ.get("MIPHEI_DBG_LIB") == "1":
+    # measurement runs only: the same tests against libmiphei_hip_dbg.so (make -C miphei-vit_amd/csrc dbg), whose dispatch knobs read
+    # the environment (MVIT_GEMM_WS, MVIT_GEMM_WS_PF, ...): lets a kernel variant be validated before it becomes the product default
+    from miphei_vit_amd import _lib as _mvit_lib
+    _mvit_lib.LIB_PATH = _mvit_lib.LIB_PATH.replace("libmiphei_hip.so", "libmiphei_hip_dbg.so")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
