@@ -19,6 +19,11 @@ template <int NVF>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, bf16_t* __restrict__ out, int M, int D,
                                                      float eps) {
+  // No FMA contraction in the statistics / normalisation: the three LayerNorm forward kernels must give the SAME bits for a row (the fused
+  // kernels are checked against ln_fwd bit for bit), and hipcc otherwise contracts a*a + b*b one way in one inlined copy and the other
+  // way in the next (1-ulp flips in ~1 of 10^6 outputs, round 4).
+#pragma clang fp contract(off)
+
   constexpr int LN_MAXV = NVF ? NVF : ::LN_MAXV_GENERIC;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -82,6 +87,11 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
                                                                     const float* __restrict__ b, bf16_t* __restrict__ out,
                                                                     const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t,
                                                                     int M, int D, float eps, int R2) {
+  // No FMA contraction in the statistics / normalisation: the three LayerNorm forward kernels must give the SAME bits for a row (the fused
+  // kernels are checked against ln_fwd bit for bit), and hipcc otherwise contracts a*a + b*b one way in one inlined copy and the other
+  // way in the next (1-ulp flips in ~1 of 10^6 outputs, round 4).
+#pragma clang fp contract(off)
+
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const int RS = D * 2 + 16;                          // padded row image (bytes)
   char* As = lds_raw;                                 // [16][RS]: AcatT rows (rows >= R2 zero)
@@ -183,6 +193,11 @@ __global__ __launch_bounds__(1024) void ln_fwd_lora2_kernel(const float* __restr
                                                             const float* __restrict__ b, bf16_t* __restrict__ out,
                                                             const bf16_t* __restrict__ AcatT, bf16_t* __restrict__ t,
                                                             int M, int D, float eps, int R2, int rows_per_block) {
+  // No FMA contraction in the statistics / normalisation: the three LayerNorm forward kernels must give the SAME bits for a row (the fused
+  // kernels are checked against ln_fwd bit for bit), and hipcc otherwise contracts a*a + b*b one way in one inlined copy and the other
+  // way in the next (1-ulp flips in ~1 of 10^6 outputs, round 4).
+#pragma clang fp contract(off)
+
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const int RS = D * 2 + 16;                          // padded row image (bytes)
   char* As = lds_raw;                                 // [16][RS]: AcatT rows (rows >= R2 zero)
