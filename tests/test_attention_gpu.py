@@ -73,3 +73,32 @@ def test_attention_backward_near_uniform_scores():
     assert e_q < 2e-2 and _rel(dqkv[:, :, 1].float(), x.grad[:, :, 1]) < 1e-2, e_q
     ops.attention_bwd(qkv, out, dO, lse, dsum, dqkv, B, N, H, Dh, scale)
     assert _rel(dqkv[:, :, 0].float(), x.grad[:, :, 0]) > 3 * e_q      # what the residual buys
+
+
+def test_attention_is_run_to_run_identical_at_the_benchmark_shape():
+    """B = 16, N = 329, H = 24, Dh = 64 (BASELINE configs[1]): the same launch repeated must give the same bits.  Round 4 found the forward
+    kernel returning, in ~2.5 % of launches, one 32-query slab with wrong output columns 32..63 (lse intact; 10-20 % off) -- invisible to
+    tolerance tests over the whole tensor, visible as run-to-run differences (tools/debug/attn_race.py).  400 forward and 200 backward
+    launches: the old kernel fails this with probability 1 - 4e-5."""
+    import miphei_vit_amd.ops as ops
+    B, N, H, Dh = 16, 329, 24, 64
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = torch.randn(B, N, 3, H, Dh, generator=g, device="cuda").bfloat16()
+    scale = Dh ** -0.5
+    out0, res0 = (torch.empty(B, N, H * Dh, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    lse0 = torch.empty(B, H, N, device="cuda")
+    ops.attention_fwd(qkv, out0, lse0, B, N, H, Dh, scale, out_res=res0)
+    bad = 0
+    for _ in range(400):
+        out, res, lse = torch.empty_like(out0), torch.empty_like(res0), torch.empty_like(lse0)
+        ops.attention_fwd(qkv, out, lse, B, N, H, Dh, scale, out_res=res)
+        bad += int(not (torch.equal(out, out0) and torch.equal(res, res0) and torch.equal(lse, lse0)))
+    assert bad == 0, f"{bad} of 400 forward launches differ from the first"
+    dO = torch.randn(B, N, H * Dh, generator=g, device="cuda").bfloat16()
+    dq0, ds0 = torch.zeros_like(qkv), torch.empty(B, H, N, device="cuda")
+    ops.attention_bwd(qkv, out0, dO, lse0, ds0, dq0, B, N, H, Dh, scale, out_res=res0)
+    for _ in range(200):
+        dq, ds = torch.zeros_like(qkv), torch.empty_like(ds0)
+        ops.attention_bwd(qkv, out0, dO, lse0, ds, dq, B, N, H, Dh, scale, out_res=res0)
+        bad += int(not (torch.equal(dq, dq0) and torch.equal(ds, ds0)))
+    assert bad == 0, f"{bad} of 200 backward launches differ from the first"

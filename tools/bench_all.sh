@@ -1,11 +1,11 @@
 #!/bin/bash
 # Measurement pass on the GPU box: every bench line DESIGN.md quotes, the rocprofv3 kernel statistics and the two PMC passes of
 # the headline command.  Writes gpurun_out/<tag>/ (scratch) and, with COPY=1 (default), the summaries into profiles/<round>_*.
-#   gpurun --timeout 1800 -- 'bash tools/bench_all.sh r03'
+#   gpurun --timeout 1800 -- 'bash tools/bench_all.sh r04'
 # Every line is produced by bench.py itself (one JSON object per file), so a claim in DESIGN.md can be re-run verbatim.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O profiles
+R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O profiles
 run() { out=$1; shift; python3 bench.py "$@" > $O/$out.json 2> $O/$out.err || echo "FAILED: $out" >&2; }
 run bench_train                                                                    # BASELINE configs[1], the driver's command
 run bench_train_metrics_on --metrics 1 --no-cpu-baseline
@@ -25,6 +25,8 @@ python3 tools/step_counters.py $O/trace $O/pmc_sq $O/pmc_fetch $O/pmc_write > $O
 db=$(ls $O/stats/*/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python3 tools/prof_summary.py $db 70 > $O/kernel_stats_train.txt
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > $O/pmc_traffic.txt
+# SQ counter breakdown of the GEMM / attention / LayerNorm kernels inside the step (six more --pmc passes)
+bash tools/sq_counters.sh $O/gemm_sq_counters.txt gemm_ws_kernel gemm_kernel attn_ ln_fwd_lora ln_bwd > /dev/null 2>&1
 # micro-benchmarks quoted in DESIGN.md: GEMMs with their epilogues vs hipBLASLt, attention, decoder convolutions, small kernels
 python3 tools/bench_epi.py > $O/gemm_epilogues.txt 2>/dev/null
 python3 tools/bench_vs_blas.py > $O/gemm_vs_hipblaslt.txt 2>/dev/null
@@ -32,7 +34,7 @@ python3 tools/bench_vs_blas.py > $O/gemm_vs_hipblaslt.txt 2>/dev/null
 python3 tools/bench_decoder_convs.py > $O/decoder_convs.txt 2>/dev/null
 python3 tools/bench_small.py > $O/small_kernels.txt 2>/dev/null
 if [ "${COPY:-1}" = 1 ]; then
-  for f in $O/bench_*.json $O/kernel_stats_train.txt $O/pmc_traffic.json $O/step_counters.txt $O/gemm_epilogues.txt \
+  for f in $O/bench_*.json $O/kernel_stats_train.txt $O/pmc_traffic.json $O/step_counters.txt $O/gemm_sq_counters.txt $O/gemm_epilogues.txt \
            $O/gemm_vs_hipblaslt.txt $O/attn.txt $O/decoder_convs.txt $O/small_kernels.txt; do
     [ -s "$f" ] && cp $f profiles/${R}_$(basename $f)
   done
