@@ -184,7 +184,9 @@ def test_gemm_tn_batched(nb, msplit):
 
 @pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),
                                                  (1, 24, 24, 72, 32, 1), (3, 8, 8, 1728, 256, 1),
-                                                 (1, 64, 64, 48, 128, 1), (2, 72, 72, 40, 96, 2)])  # 256-row conv tiles
+                                                 (1, 64, 64, 48, 128, 1), (2, 72, 72, 40, 96, 2),   # 256-row conv tiles
+                                                 # the three stride-2 ConvStream layers at their real sizes (mipheivit.py:59-64), B = 2
+                                                 (2, 256, 256, 8, 48, 2), (2, 128, 128, 48, 96, 2), (2, 64, 64, 96, 192, 2)])
 def test_conv3x3_fwd_stats_and_dgrad(B, H, W, C, Cout, stride):
     ops = _ops()
     x = _rand(B, H, W, C, seed=1).bfloat16()  # NHWC
@@ -265,7 +267,8 @@ def test_gemm_tn_batched(nb, msplit):
 
 
 @pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),
-                                                 (1, 24, 24, 72, 32, 1), (2, 8, 8, 1728, 256, 1)])
+                                                 (1, 24, 24, 72, 32, 1), (2, 8, 8, 1728, 256, 1),
+                                                 (2, 256, 256, 8, 48, 2), (2, 128, 128, 48, 96, 2), (2, 64, 64, 96, 192, 2)])   # ConvStream layers
 def test_gemm_tn_conv_wgrad(B, H, W, C, Cout, stride):
     ops = _ops()
     x = _rand(B, H, W, C, seed=1).bfloat16()
