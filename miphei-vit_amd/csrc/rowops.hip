@@ -422,16 +422,19 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const uint4 zero = make_uint4(0, 0, 0, 0);
   const unsigned xmask = rok ? 0xffffffffu : 0u, wmask = wok ? 0xffffffffu : 0u;
-  int k = wave * 32;                       // this wave's k-steps: wave, wave + 4, wave + 8, ...
-  constexpr int U = 6;                     // k-steps in flight per wave (K = 1536: 12 per wave = two full rounds; 4 and 12 measure the same)
-  for (; k + (U - 1) * 128 + 32 <= K; k += U * 128) {
+  // This wave's k-steps come in PAIRS that share a 128-byte line of every row (steps 2j and 2j + 1 of line j = wave, wave + 4, ...): a
+  // wave's load instruction covers 64 bytes of 16 rows, so with the former interleave (step = wave, wave + 4, ...) every line of X was
+  // fetched by two different waves, half each (round 4: 12.5 -> see profiles/r04_small_kernels.txt)
+  int k = wave * 64;
+  constexpr int U = 6;                     // k-steps in flight per wave (three lines)
+  for (; k + (U / 2 - 1) * 256 + 64 <= K; k += (U / 2) * 256) {
     // unconditional loads (the pointers of rows / adapter columns outside the problem were clamped to row 0 above), masked
     // afterwards: `rok ? load : zero` makes hipcc branch around each load and wait for it (three round trips per six k-steps)
     uint4 xa[U], wb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      xa[u] = *(const uint4*)(xp + k + 128 * u);
-      wb[u] = *(const uint4*)(wp + k + 128 * u);
+      xa[u] = *(const uint4*)(xp + k + 256 * (u >> 1) + 32 * (u & 1));
+      wb[u] = *(const uint4*)(wp + k + 256 * (u >> 1) + 32 * (u & 1));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -440,11 +443,15 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&xa[u], *(bf16x8*)&wb[u], acc, 0, 0, 0);
     }
   }
-  for (; k < K; k += 128) {
-    const bool kok = k + kq * 8 < K;
-    const uint4 xa = (rok && kok) ? *(const uint4*)(xp + k) : zero;
-    const uint4 wb = (wok && kok) ? *(const uint4*)(wp + k) : zero;
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&xa, *(const bf16x8*)&wb, acc, 0, 0, 0);
+  for (; k < K; k += 256) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int kk = k + 32 * h2;
+      const bool kok = kk + kq * 8 < K;
+      const uint4 xa = (rok && kok) ? *(const uint4*)(xp + kk) : zero;
+      const uint4 wb = (wok && kok) ? *(const uint4*)(wp + kk) : zero;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&xa, *(const bf16x8*)&wb, acc, 0, 0, 0);
+    }
   }
   if (wave > 0) {
 #pragma unroll
