@@ -195,6 +195,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   for (int t = 0; t < my_tiles; ++t, vt += gridDim.x) {
     int m0, n0;
     ord.get(vt, m0, n0);
+    if (m0 + wave_m * WTM >= p.M) {
+      // this wave's 64 rows lie entirely beyond M (ragged last tile row: rows 192.. of a tile with 144 valid rows at M = 5264): it only
+      // keeps the block's barriers -- no fragment reads, no MFMAs on zero rows (the loops are power-limited: work that is not done is clock)
+      for (int k = 0; k < nk; ++k) {
+        __builtin_amdgcn_s_barrier();                    // B(g)
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+      }
+      __builtin_amdgcn_s_barrier();                      // B'(tile)
+      continue;
+    }
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
