@@ -15,6 +15,9 @@
 //     landed K tile through the block barrier the K step already has.  They run two K tiles ahead, across tile boundaries.
 // One s_barrier per K tile (all 12 waves), one more per output tile (the epilogue panel lives in the LDS stage consumed last).
 // Three waves per SIMD -> at most 168 VGPRs per lane (MI355X_MICROARCH.md, register table).
+// Band mode (BAND instantiations): when the partly empty last tile row would cost a whole extra round of tiles, the whole 256-row tile
+// rows run as whole rounds and the ragged band runs as 64-row x 128-column items, one per block, behind the block's last tile (same
+// pipeline, 16-row wave sub-tiles): fc1 + SwiGLU of the batch-16 step 136.4 -> 129.8 us in the step.
 //
 // LDS image of a stage, fragment addressing, the XOR swizzle on the DMA source address and the tile order are those of
 // gemm_kernel.hpp (so are the epilogue formulas: STORE / SWIGLU / RESID / DSWIGLU, vector paths only; everything else -- unaligned
@@ -66,27 +69,40 @@ struct TileOrder {   // virtual tile id -> XCD-aware, grouped (8 tile rows x all
   }
 };
 
-template <int EPI>
+// BAND: the kernel also takes the 64-row items of the ragged band (see the work plan below); instantiated for the epilogues whose
+// shapes need it (store, SwiGLU) -- the residual kernel sits at 168 VGPRs without it
+template <int EPI, bool BAND>
 __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Work plan of a block: its tiles of the persistent walk (vt = blockIdx.x, + gridDim.x, ...) and, in BAND mode (flag 0x2000, set by
+  // the dispatcher when the partly empty last tile row would cost a whole extra round of tiles: fc1 of the batch-16 step, 21 x 64 =
+  // 1344 tiles = 5.25 rounds on 256 CUs), at most one 64-row x 128-column ITEM of the ragged band at the end of the walk: the full
+  // tile rows are then exactly the whole rounds, and the band (144 rows at M = 5264: 3 x 64 items per tile column, 192 items) runs as
+  // one short extra step per block -- a quarter of a tile's MFMAs, half of its DMA bytes -- instead of a sixth round on 64 of 256 CUs.
+  const bool band = BAND && (p.flags & 0x2000) != 0;
+  const int rows_full = band ? p.M / BM * BM : 0;                          // rows covered by whole 256-row tiles in band mode
+  const int nq = band ? (p.M - rows_full + 63) / 64 : 0;                   // 64-row items per tile column of the band
   TileOrder ord;
-  ord.tiles_m = (p.M + BM - 1) / BM;
+  ord.tiles_m = band ? p.M / BM : (p.M + BM - 1) / BM;
   ord.tiles_n = p.N / BN;
   ord.ntiles = ord.tiles_m * ord.tiles_n;
   const int nk1 = p.K / BK;
   const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
   const int nk = nk1 + nk2;
   const int my_tiles = ((int)blockIdx.x < ord.ntiles) ? (ord.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int G = my_tiles * nk;   // K tiles this block walks (global step index g = tile * nk + k)
+  const bool has_item = BAND && (int)blockIdx.x < nq * ord.tiles_n;                // band item of this block: column bx / nq, quarter bx % nq
+  const int item_m = rows_full + ((int)blockIdx.x % (nq > 0 ? nq : 1)) * 64, item_n = ((int)blockIdx.x / (nq > 0 ? nq : 1)) * BN;
+  const int G = (my_tiles + (has_item ? 1 : 0)) * nk;   // K tiles this block walks (global step index g)
 
   if (wave >= NCW) {
     // ================================================================ producers
     const int pw = wave - NCW;
     // per-lane source offsets of this wave's pieces (tile independent: the tile enters through the descriptor's base; the K advance
     // rides on the scalar offset, which is outside the range check -- every row is a whole multiple of 128 B wide here)
-    unsigned voA[PA], voB[PB], voA2[PA], voB2[PB];
+    constexpr int PAQ = 64 / 8 / NPW;                    // A pieces per producer wave of a 64-row band item = 2
+    unsigned voA[PA], voB[PB], voA2[PA], voB2[PB], voAq[PAQ], voAq2[PAQ];
     const int rl = lane >> 3, c8 = lane & 7;
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
@@ -96,6 +112,13 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       voA2[j] = (cs * 8 < p.K2) ? (unsigned)row * (unsigned)p.lda2 * 2u + (unsigned)cs * 16u : OOB;   // (K2 < 64: the valid chunks)
     }
 #pragma unroll
+    for (int j = 0; j < PAQ; ++j) {
+      const int row = (pw * PAQ + j) * 8 + rl;
+      const int cs = c8 ^ ((row >> 1) & 7);
+      voAq[j] = (unsigned)row * (unsigned)p.lda * 2u + (unsigned)cs * 16u;
+      voAq2[j] = (cs * 8 < p.K2) ? (unsigned)row * (unsigned)p.lda2 * 2u + (unsigned)cs * 16u : OOB;
+    }
+#pragma unroll
     for (int j = 0; j < PB; ++j) {
       const int row = (pw * PB + j) * 8 + rl;
       const int cs = c8 ^ ((row >> 1) & 7);
@@ -103,70 +126,100 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       voB2[j] = (cs * 8 < p.K2) ? (unsigned)row * (unsigned)p.ldb2 * 2u + (unsigned)cs * 16u : OOB;
     }
     __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2;
-    auto set_tile = [&](int vt) __attribute__((always_inline)) {
-      int m0, n0;
-      ord.get(vt, m0, n0);
-      const unsigned vm = (unsigned)min(BM, p.M - m0), vn = (unsigned)min(BN, p.N - n0);
-      // num_records = the valid rows of this tile: rows beyond M / N read as zero (hardware range check on the vector offset)
+    // descriptors of work unit `idx` of this block (idx < my_tiles: a tile of the walk; idx == my_tiles: the band item)
+    auto set_unit = [&](int idx) __attribute__((always_inline)) {
+      int m0, n0, rows;
+      if (idx < my_tiles) {
+        ord.get(blockIdx.x + idx * gridDim.x, m0, n0);
+        rows = BM;
+      } else {
+        m0 = item_m, n0 = item_n, rows = 64;
+      }
+      const unsigned vm = (unsigned)min(rows, p.M - m0), vn = (unsigned)min(BN, p.N - n0);
+      // num_records = the valid rows of this unit: rows beyond M / N read as zero (hardware range check on the vector offset)
       rsA = make_rsrc((const bf16_t*)p.A + (size_t)m0 * p.lda, vm * (unsigned)p.lda * 2u);
       rsB = make_rsrc((const bf16_t*)p.B + (size_t)n0 * p.ldb, vn * (unsigned)p.ldb * 2u);
       rsA2 = make_rsrc(p.A2 ? (const bf16_t*)p.A2 + (size_t)m0 * p.lda2 : (const bf16_t*)p.A, p.A2 ? vm * (unsigned)p.lda2 * 2u : 0u);
       rsB2 = make_rsrc(p.B2 ? (const bf16_t*)p.B2 + (size_t)n0 * p.ldb2 : (const bf16_t*)p.B, p.B2 ? vn * (unsigned)p.ldb2 * 2u : 0u);
     };
     // (generic lambda: the DMA builtin exists for the device target only, see gemm_kernel.hpp)
-    auto issue = [&](int k, int stage, auto) __attribute__((always_inline)) {
+    auto issue = [&](int k, int stage, bool item, auto) __attribute__((always_inline)) {
       if (MVIT_WS_ABLATE & 1) return;
-      char* a = smem + stage * BUF_BYTES + pw * PA * 1024;
       char* b = smem + stage * BUF_BYTES + A_BYTES + pw * PB * 1024;
-      if (k < nk1) {
-        const int soff = k * (BK * 2);
+      const int soff = k < nk1 ? k * (BK * 2) : 0;
+      // second K range (k >= nk1; LoRA: A2 = t [M, 2r], B2 = [N, 2r]): chunks at or beyond K2 are zero (OOB offsets above; K2 <= 64)
+      if (!BAND || !item) {
+        char* a = smem + stage * BUF_BYTES + pw * PA * 1024;
+        if (k < nk1) {
 #pragma unroll
-        for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 1024), 16, voA[j], soff, 0, 0);
+          for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 1024), 16, voA[j], soff, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 1024), 16, voA2[j], 0, 0, 0);
+        }
+      } else {
+        char* a = smem + stage * BUF_BYTES + pw * PAQ * 1024;      // the item's 64 A rows are rows 0..63 of the stage's A image
+        if (k < nk1) {
+#pragma unroll
+          for (int j = 0; j < PAQ; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 1024), 16, voAq[j], soff, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < PAQ; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 1024), 16, voAq2[j], 0, 0, 0);
+        }
+      }
+      if (k < nk1) {
 #pragma unroll
         for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * 1024), 16, voB[j], soff, 0, 0);
       } else {
-        // second K range (LoRA: A2 = t [M, 2r], B2 = [N, 2r]); chunks at or beyond K2 are zero (OOB offsets above, first K tile of
-        // the range only: K2 <= 64 is what the dispatcher admits)
-#pragma unroll
-        for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 1024), 16, voA2[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * 1024), 16, voB2[j], 0, 0, 0);
       }
     };
     // look-ahead cursor: the next K tile to request
-    int l_vt = blockIdx.x, l_k = 0, l_stage = 0, l_g = 0;
-    if (G > 0) set_tile(l_vt);
+    int l_unit = 0, l_k = 0, l_stage = 0, l_g = 0;
+    bool l_item = my_tiles == 0;                          // the unit under the cursor is the band item (12 vs 6 pieces per request)
+    if (G > 0) set_unit(0);
+    bool last_item = false;                               // kind of the request made last (its pieces are what may stay in flight)
     auto issue_next = [&](auto tag) __attribute__((always_inline)) {
-      issue(l_k, l_stage, tag);
+      issue(l_k, l_stage, l_item, tag);
+      last_item = l_item;
       ++l_g;
       l_stage = l_stage + 1 == NSTAGE ? 0 : l_stage + 1;
       if (++l_k == nk) {
         l_k = 0;
-        l_vt += gridDim.x;
-        if (l_g < G) set_tile(l_vt);
+        ++l_unit;
+        l_item = l_unit >= my_tiles;
+        if (l_g < G) set_unit(l_unit);
       }
+    };
+    // everything but the request just made has landed
+    auto wait_older = [&]() __attribute__((always_inline)) {
+      if (BAND && last_item)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PAQ + PB) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     };
     if (G > 0) issue_next(0);
     if (G > 1) {
       issue_next(0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      wait_older();
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                        // B(-1): K tile 0 has landed
     int g = 0;
-    for (int t = 0; t < my_tiles; ++t) {
+    for (int t = 0; t < my_tiles + (has_item ? 1 : 0); ++t) {
       for (int k = 0; k < nk; ++k, ++g) {
         // stage (g + 2) % 3 = the one consumed in step g - 1: free since the barrier that ended it
         if (g + 2 < G) {
           issue_next(0);
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // everything but the request just made: K tile g + 1 is in LDS
+          wait_older();                                  // K tile g + 1 is in LDS
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                    // B(g)
       }
-      __builtin_amdgcn_s_barrier();                      // B'(tile): the consumers are done with the epilogue panel (= stage of step g - 1)
+      __builtin_amdgcn_s_barrier();                      // B'(unit): the consumers are done with the epilogue panel (= stage of step g - 1)
     }
     return;
   }
@@ -174,13 +227,6 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   // ================================================================== consumers
   const int wave_m = wave >> 1, wave_n = wave & 1;
   const int fr = lane & 15, fh = lane >> 4;            // fragment row, 16-byte K chunk inside a 32-wide sub-step
-  unsigned aoff[2], boff[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const unsigned sw = (unsigned)(((s * 4 + fh) ^ ((fr >> 1) & 7)) << 4);
-    aoff[s] = (unsigned)(wave_m * WTM + fr) * 128u + sw;
-    boff[s] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + fr) * 128u + sw;
-  }
   const bool out_f32 = p.flags & MVIT_OUT_F32;
   float* Cf = (float*)p.C;
   bf16_t* Cb = (bf16_t*)p.C;
@@ -191,37 +237,44 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 
   __builtin_amdgcn_s_barrier();                          // B(-1)
   int stage = 0;
-  int vt = blockIdx.x;
-  for (int t = 0; t < my_tiles; ++t, vt += gridDim.x) {
-    int m0, n0;
-    ord.get(vt, m0, n0);
-    if (m0 + wave_m * WTM >= p.M) {
-      // this wave's 64 rows lie entirely beyond M (ragged last tile row: rows 192.. of a tile with 144 valid rows at M = 5264): it only
+  // One work unit: a 256 x 128 tile (TMc = 4: 64-row wave sub-tiles) or a 64 x 128 item of the ragged band (TMc = 1: 16-row sub-tiles,
+  // the A image uses rows 0..63 of the stage); m_base / n0 = its first row / column
+  auto run_unit = [&](auto tm_tag, int m_base, int n0) __attribute__((always_inline)) {
+    constexpr int TMc = decltype(tm_tag)::value;
+    unsigned aoff[2], boff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned sw = (unsigned)(((s * 4 + fh) ^ ((fr >> 1) & 7)) << 4);
+      aoff[s] = (unsigned)(wave_m * (16 * TMc) + fr) * 128u + sw;
+      boff[s] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + fr) * 128u + sw;
+    }
+    if (m_base + wave_m * (16 * TMc) >= p.M) {
+      // this wave's rows lie entirely beyond M (ragged last tile row: rows 192.. of a tile with 144 valid rows at M = 5264): it only
       // keeps the block's barriers -- no fragment reads, no MFMAs on zero rows (the loops are power-limited: work that is not done is clock)
       for (int k = 0; k < nk; ++k) {
         __builtin_amdgcn_s_barrier();                    // B(g)
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
       }
-      __builtin_amdgcn_s_barrier();                      // B'(tile)
-      continue;
+      __builtin_amdgcn_s_barrier();                      // B'(unit)
+      return;
     }
-    f32x4 acc[TM][TN];
+    f32x4 acc[TMc][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMc; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[2][TM], fb[2][TN];
+    bf16x8 fa[2][TMc], fb[2][TN];
     {
       const char* cur = smem + stage * BUF_BYTES;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[0][i] = *(const bf16x8*)(cur + aoff[0] + i * 2048);
+      for (int i = 0; i < TMc; ++i) fa[0][i] = *(const bf16x8*)(cur + aoff[0] + i * 2048);
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[0][j] = *(const bf16x8*)(cur + boff[0] + j * 2048);
     }
     // One K tile: sub-step 0 (16 MFMAs) carries the eight fragment reads of sub-step 1, one behind every other MFMA, in the order
     // sub-step 1 consumes them (a0, b0..b3, a1..a3); sub-step 1 runs six MFMAs, hands the stage over (its reads are back: lgkmcnt(0),
     // block barrier = the next K tile has landed, see the producers) and carries the first fragments of the next stage on the rest.
-    auto read_sub = [&](const char* base, int s, int r, bf16x8 (&xa)[TM], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
+    auto read_sub = [&](const char* base, int s, int r, bf16x8 (&xa)[TMc], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
       if (r == 0)
         xa[0] = *(const bf16x8*)(base + aoff[s]);
       else if (r <= TN)
@@ -229,18 +282,23 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       else
         xa[r - TN] = *(const bf16x8*)(base + aoff[s] + (r - TN) * 2048);
     };
+    constexpr int NM = TMc * TN, NR = TMc + TN;          // MFMAs / fragment reads per sub-step
     auto kstep = [&](auto more_tag) __attribute__((always_inline)) {
       constexpr bool more = decltype(more_tag)::value;   // another K tile of THIS output tile follows
       const char* cur = smem + stage * BUF_BYTES;
 #pragma unroll
-      for (int m = 0; m < TM * TN; ++m) {
+      for (int m = 0; m < TMc * TN; ++m) {
         const int i = m / TN, j = m % TN;
         if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
         else asm volatile("" ::"v"(fa[0][i]), "v"(fb[0][j]));
-        if ((m & 1) == 0 && !(MVIT_WS_ABLATE & 4)) read_sub(cur, 1, m >> 1, fa[1], fb[1]);
+        if (!(MVIT_WS_ABLATE & 4)) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r)      // reads spread over the MFMAs: ceil((m + 1) NR / NM) issued by MFMA m
+            if (r >= (m * NR + NM - 1) / NM && r < ((m + 1) * NR + NM - 1) / NM) read_sub(cur, 1, r, fa[1], fb[1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      constexpr int HO = 6;
+      constexpr int HO = TMc == 4 ? 6 : 1;
 #pragma unroll
       for (int m = 0; m < HO; ++m) {
         const int i = m / TN, j = m % TN;
@@ -254,11 +312,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       stage = stage + 1 == NSTAGE ? 0 : stage + 1;
       const char* nxt = smem + stage * BUF_BYTES;
 #pragma unroll
-      for (int m = HO; m < TM * TN; ++m) {
+      for (int m = HO; m < TMc * TN; ++m) {
         const int i = m / TN, j = m % TN;
         if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         else asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][j]));
-        if (more && m - HO < TM + TN && !(MVIT_WS_ABLATE & 4)) read_sub(nxt, 0, m - HO, fa[0], fb[0]);
+        if (more && !(MVIT_WS_ABLATE & 4)) {
+          constexpr int NM2 = NM - HO;
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            if (r >= ((m - HO) * NR + NM2 - 1) / NM2 && r < ((m - HO + 1) * NR + NM2 - 1) / NM2) read_sub(nxt, 0, r, fa[0], fb[0]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -290,23 +353,13 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     constexpr bool AUX = (EPI == MVIT_EPI_RESID || EPI == MVIT_EPI_DSWIGLU);
     // per-element operands of the whole sub-tile (residual stream / saved pre-activation) are requested up front: the fragment
     // registers are dead here, and a load requested behind a store would wait for that store too (one counter, see the header)
-    uint4 pre[TM][NPASS][2];
-    float rsc_[TM][NPASS];                               // DropPath factor of each row's sample (residual epilogue; 1 without rowscale)
-    if constexpr (EPI == MVIT_EPI_RESID) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int it = 0; it < NPASS; ++it) {
-          const int row = m0 + wave_m * WTM + i * 16 + it * RPP + lr;
-          rsc_[i][it] = p.rowscale ? p.rowscale[row < p.M ? row : p.M - 1] : 1.f;
-        }
-    }
+    uint4 pre[TMc][NPASS][2];
     if constexpr (AUX) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TMc; ++i)
 #pragma unroll
         for (int it = 0; it < NPASS; ++it) {
-          const int row = m0 + wave_m * WTM + i * 16 + it * RPP + lr;
+          const int row = m_base + wave_m * (16 * TMc) + i * 16 + it * RPP + lr;
           const int rr = row < p.M ? row : p.M - 1;      // (clamped: an unconditional load, results of rows >= M are not stored)
           if constexpr (EPI == MVIT_EPI_RESID) {
             const float* rp = p.aux ? (const float*)p.aux + (size_t)rr * p.ldaux + col : Cf + (size_t)rr * p.ldc + col;
@@ -332,7 +385,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
     };
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TMc; ++i) {
       // park rows 16 i .. 16 i + 15 of the sub-tile (C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + register)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -345,7 +398,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 #pragma unroll
       for (int it = 0; it < NPASS; ++it) {
         const int rl_ = it * RPP + lr;
-        const int row = m0 + wave_m * WTM + i * 16 + rl_;
+        const int row = m_base + wave_m * (16 * TMc) + i * 16 + rl_;
         const bool rok = row < p.M;
         if constexpr (EPI == MVIT_EPI_SWIGLU) {
           float a_[V], b_[V], g_[V];
@@ -388,9 +441,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
             const uint4 t0 = pre[i][it][0], t1 = pre[i][it][1];
             float r_[V] = {__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w),
                            __uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w)};
-            const float rsc = rsc_[i][it];
 #pragma unroll
-            for (int e = 0; e < V; ++e) r_[e] += rsc * gam[e] * v[e];
+            for (int e = 0; e < V; ++e) r_[e] += gam[e] * v[e];     // (DropPath row factors: gemm_kernel.hpp, see ws_supported)
             if (rok) {
               float* dst = Cf + (size_t)row * p.ldc + col;
               ((float4*)dst)[0] = make_float4(r_[0], r_[1], r_[2], r_[3]);
@@ -418,7 +470,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         }
       }
     }
-    __builtin_amdgcn_s_barrier();                        // B'(tile): the panel stage may be refilled
+    __builtin_amdgcn_s_barrier();                        // B'(unit): the panel stage may be refilled
+  };
+  int vt = blockIdx.x;
+  for (int t = 0; t < my_tiles; ++t, vt += gridDim.x) {
+    int m0, n0;
+    ord.get(vt, m0, n0);
+    run_unit(std::integral_constant<int, 4>{}, m0, n0);
+  }
+  if constexpr (BAND) {
+    if (has_item) run_unit(std::integral_constant<int, 1>{}, item_m, item_n);
   }
 }
 
@@ -426,11 +487,11 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 
 // problems the wave-specialised kernel takes (everything else stays on gemm_kernel.hpp)
 bool ws_supported(const mvit_gemm_args& a) {
-  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800))) return false;
+  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000))) return false;
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_SWIGLU && a.epi != MVIT_EPI_RESID && a.epi != MVIT_EPI_DSWIGLU) return false;
   if (a.M < 1024 || (a.N % 128) || (a.K % 64) || a.K < 64) return false;
   if (a.A2 && (a.K2 > 64 || a.K2 <= 0)) return false;
-  if (a.epi == MVIT_EPI_RESID && !(a.flags & MVIT_OUT_F32)) return false;
+  if (a.epi == MVIT_EPI_RESID && (!(a.flags & MVIT_OUT_F32) || a.rowscale)) return false;   // (DropPath row factors: 8 more registers than the 168 this kernel has)
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_RESID && (a.flags & MVIT_OUT_F32)) return false;
   if (a.epi != MVIT_EPI_STORE && (a.flags & MVIT_ACCUM_BF16)) return false;
   // 32-bit byte offsets inside a tile's descriptor range
@@ -439,25 +500,43 @@ bool ws_supported(const mvit_gemm_args& a) {
   return true;
 }
 
-template <int EPI>
+template <int EPI, bool BAND>
 static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN);
   const size_t lds = (size_t)ws::NSTAGE * ws::BUF_BYTES;
   int gx = gemm_num_cus();
   if (gx > tiles) gx = tiles;
-  auto kern = ws::gemm_ws_kernel<EPI>;
+  auto kern = ws::gemm_ws_kernel<EPI, BAND>;
   static mvit_per_device_size raised;
   if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return MVIT_EINVAL;
   hipLaunchKernelGGL(kern, dim3(gx), dim3(64 * (ws::NCW + ws::NPW)), lds, s, a);
   return MVIT_LAUNCH_CHECK();
 }
 
-int launch_ws(const mvit_gemm_args& a, hipStream_t s) {
+// Band mode pays when the partly empty last tile row is what pushes the launch into another round of tiles: whole tile rows = whole
+// rounds, band items <= one per block.  (fc1 of the batch-16 training step: M = 5264, N = 8192 -> 1280 tiles = 5 rounds + 192 items.)
+bool ws_band_mode(const mvit_gemm_args& a) {
+  if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_SWIGLU) return false;
+  const long long cus = gemm_num_cus(), nt = a.N / ws::BN, rf = a.M / ws::BM;
+  const int tail = a.M - (int)rf * ws::BM;
+  if (tail <= 0 || rf <= 0) return false;
+  const long long rounds_all = ((rf + 1) * nt + cus - 1) / cus, rounds_full = (rf * nt + cus - 1) / cus;
+  const long long items = (long long)((tail + 63) / 64) * nt;
+  return rounds_full < rounds_all && (rf * nt) % cus == 0 && items <= cus;
+}
+
+int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob) {
+  mvit_gemm_args a = a0;
+  a.flags &= ~0x2000;
+  if (band_knob && ws_band_mode(a)) {
+    a.flags |= 0x2000;
+    return a.epi == MVIT_EPI_STORE ? launch_ws_one<MVIT_EPI_STORE, true>(a, s) : launch_ws_one<MVIT_EPI_SWIGLU, true>(a, s);
+  }
   switch (a.epi) {
-    case MVIT_EPI_STORE: return launch_ws_one<MVIT_EPI_STORE>(a, s);
-    case MVIT_EPI_SWIGLU: return launch_ws_one<MVIT_EPI_SWIGLU>(a, s);
-    case MVIT_EPI_RESID: return launch_ws_one<MVIT_EPI_RESID>(a, s);
-    case MVIT_EPI_DSWIGLU: return launch_ws_one<MVIT_EPI_DSWIGLU>(a, s);
+    case MVIT_EPI_STORE: return launch_ws_one<MVIT_EPI_STORE, false>(a, s);
+    case MVIT_EPI_SWIGLU: return launch_ws_one<MVIT_EPI_SWIGLU, false>(a, s);
+    case MVIT_EPI_RESID: return launch_ws_one<MVIT_EPI_RESID, false>(a, s);
+    case MVIT_EPI_DSWIGLU: return launch_ws_one<MVIT_EPI_DSWIGLU, false>(a, s);
     default: return MVIT_EINVAL;
   }
 }

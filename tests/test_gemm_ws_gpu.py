@@ -27,7 +27,7 @@ def _is_ws(M, N, K, epi=0, flags=0, K2=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(5264, 1536, 1536), (5264, 4608, 64), (1024, 128, 128), (2303, 384, 4608), (5264, 4608, 1536),
-                                   (70000, 128, 192), (5264, 8192, 192)])      # the last one: 1344 tiles = 5.25 rounds, ragged last tile row
+                                   (70000, 128, 192), (5264, 8192, 192)])      # the last one: 1344 tiles = 5.25 rounds -> band mode (1280 tiles + 192 band items)
 def test_ws_store(M, N, K):
     import miphei_vit_amd.ops as ops
     assert _is_ws(M, N, K)
@@ -108,3 +108,25 @@ def test_ws_swiglu_and_its_backward(M, D, H):
     da, db = dG * b_ * sg * (1 + a_ * (1 - sg)), dG * a_ * sg
     ref = torch.stack([da.view(M, H // 32, 32), db.view(M, H // 32, 32)], dim=2).reshape(M, 2 * H)
     assert _rel(du.float(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(5264, 8192, 128), (2600, 3200, 192), (5121, 8192, 64), (5183, 8192, 64), (5184, 8192, 64), (5375, 8192, 64)])
+def test_ws_band_mode_ragged_rows(M, N, K):
+    """Shapes whose partly empty last tile row would cost an extra round: the full tile rows run as whole rounds, the ragged band as
+    64-row items (one per block).  Band heights 1, 63, 64 and 255 rows around the item boundaries, store and SwiGLU epilogues."""
+    import miphei_vit_amd.ops as ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a, b, bias = _rnd(g, M, K), _rnd(g, N, K, scale=K ** -0.5), _rnd(g, N, dt=torch.float32)
+    ref = a.float() @ b.float().t() + bias
+    c = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)          # guard rows behind the output
+    ops.gemm(a, b, c[:M], bias=bias)
+    assert _rel(c[:M].float(), ref) < 4e-3 and float((c[M:].float() - 7.0).abs().max()) == 0.0
+    if N % 64 == 0:
+        H = N // 2
+        u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        gate = torch.full((M + 3, H), 5.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, b, gate[:M], bias=bias, aux=u, epi=ops.EPI_SWIGLU)
+        pre = ref.view(M, H // 32, 2, 32)
+        a_ref, b_ref = pre[:, :, 0].reshape(M, H), pre[:, :, 1].reshape(M, H)
+        assert _rel(u.float(), ref) < 4e-3
+        assert _rel(gate[:M].float(), torch.nn.functional.silu(a_ref) * b_ref) < 6e-3 and float((gate[M:].float() - 5.0).abs().max()) == 0.0
