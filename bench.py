@@ -268,12 +268,14 @@ def main(argv=None):
     # roofline leg: HIP events around the launches of the dominant kernel, on a SAMPLE of the timed steps (every probe_every-th,
     # at least one): an event pair costs the stream ~6 us of idle time per launch, which on all 159 launches of every step was
     # 2.9 % of the headline number (395 vs 406.5 tiles/s same box)
-    # Round 4: the probe samples TWO of the timed steps (the first and the middle one: 318 launches), and one event per step
-    # boundary (a marker every ~36 ms) gives the duration of every step, so the line also carries the rate of the unprobed steps
-    # (`unprobed`): at the driver's --steps 20 the former five sampled steps cost ~0.7 % of the headline, two cost ~0.25 %.
+    # Round 4: the probe samples ONE of the timed steps (the middle one: 159 launches of the dominant kernel), and one event per
+    # step boundary (a marker every ~35 ms) gives the duration of every step, so the line also carries the rate of the unprobed
+    # steps (`unprobed`).  Measured per step (`unprobed.step_ms`): a probed step in the middle of the run costs +1.0 ms, the FIRST
+    # timed step +2.6 ms when probed (the host is not yet ahead of the device there and pays 318 event creations on the critical
+    # path): five sampled steps of 20 cost the headline ~0.7 %, steps {0, K/2} 0.5 %, the middle step alone 0.15 %.
     ops.PROBE.start()
     ops.PROBE.on = False
-    probed = sorted({0, a.steps // 2}) if a.probe else []
+    probed = [a.steps // 2] if a.probe else []
     probe_every = max(1, a.steps // 2)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
@@ -326,7 +328,7 @@ def main(argv=None):
                    "global_batch": world * a.batch, "img": a.img, "parallelism": f"dp{world}", "pix_metrics": bool(a.metrics)},
     }
     res["unprobed"] = {"ms_per_step": round(sum(free_ms) / len(free_ms), 3), "tiles_per_s": round(a.batch * world * len(free_ms) / (sum(free_ms) * 1e-3), 2),
-                       "steps": len(free_ms), "probed_steps": len(probed),
+                       "steps": len(free_ms), "probed_steps": len(probed), "step_ms": [round(t, 2) for t in step_ms],
                        "note": "this rank's timed steps that carried no HIP-event probe (step-boundary events on the compute stream); "
                                "`value` is the contract number over ALL timed steps, probe overhead included"}
     if dist.is_initialized():
