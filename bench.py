@@ -423,9 +423,15 @@ def pmc_traffic_all():
                 k = json.load(f)["kernels"]
         except Exception:  # noqa: BLE001
             continue
+        best = {}
         for kn, v in k.items():
             key = kn.replace("void ", "").replace("mvit_gemm::", "").strip()
             out[key] = round(v["hbm_bytes_per_launch_corrected"])
+            if "gemm_ws_kernel<" in key:      # 'ws::gemm_ws_kernel<2, true>' (epilogue, band mode) -> alias 'ws::gemm_ws_kernel<2>'
+                alias = key.split(",")[0] + ">"
+                if v.get("launches", 0) > best.get(alias, -1):
+                    best[alias] = v.get("launches", 0)
+                    out[alias] = out[key]
         if "attn_bwd_dq_kernel" in out and "attn_bwd_dkv_kernel" in out:
             out["attn_bwd (all launches of mvit_attention_bwd)"] = sum(v for kk, v in out.items() if kk.startswith("attn_bwd_"))
         return out
@@ -445,7 +451,7 @@ def pmc_traffic(kernel="gemm_kernel<256, 128, 4, 2, 0, 0>"):
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 k = json.load(f)["kernels"]
             for kn, v in k.items():
-                if kernel in kn:
+                if kernel in kn or kernel.rstrip(">") + "," in kn:
                     return round(v["hbm_bytes_per_launch_corrected"]), f"profiles/{name} (static: committed rocprofv3 --pmc passes)"
         except Exception:  # noqa: BLE001
             continue
