@@ -298,7 +298,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      constexpr int HO = TMc == 4 ? 6 : 1;
+#ifndef MVIT_WS_HO
+#define MVIT_WS_HO 6
+#endif
+      constexpr int HO = TMc == 4 ? MVIT_WS_HO : 1;   // MFMAs of sub-step 1 ahead of the hand-over (measured: 2 / 6 / 10)
 #pragma unroll
       for (int m = 0; m < HO; ++m) {
         const int i = m / TN, j = m % TN;
