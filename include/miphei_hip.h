@@ -293,6 +293,15 @@ MVIT_API int mvit_pack_conv3x3_direct(const float* W, void* out, int Cout, int C
  *     the f32 results (BatchNorm2d batch statistics), one slot per block when nslots >= the CU count.  Cin, Cout % 8 == 0. */
 MVIT_API long long mvit_conv3x3_chunked_pack_elems(int N, int K);
 MVIT_API int mvit_conv3x3_chunked_pack(const float* W, void* out_bf16, int Cout, int Cin, int mode, mvit_stream_t stream);
+/* several such packs in one launch (the per-step operand packs of the Fusion_Block convolutions, src/generators/mipheivit.py:76-93: their
+ * weights change with every optimiser step): descs is a HOST array of n <= MVIT_CC_PACK_MAX descriptors, out buffers sized by
+ * mvit_conv3x3_chunked_pack_elems */
+#define MVIT_CC_PACK_MAX 8
+typedef struct mvit_cc_pack_desc {
+  const float* W; void* out;
+  int Cout, Cin, mode, pad_;
+} mvit_cc_pack_desc;
+MVIT_API int mvit_conv3x3_chunked_pack_multi(const mvit_cc_pack_desc* descs, int n, mvit_stream_t stream);
 MVIT_API int mvit_conv3x3_chunked(const void* X, const void* Wp, void* Y, double* stats, int nslots, int B, int H, int W, int Cin,
                                   int ldx, int Cout, int ldy, mvit_stream_t stream);
 /* Weight gradient of the same layers on the same staging: dWn(f32)[Cout][9 * Cin_pad] += sum over pixels of

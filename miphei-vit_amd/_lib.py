@@ -44,6 +44,10 @@ class ConvPackDesc(C.Structure):
     _fields_ = [("W", vp), ("wk", vp), ("wd", vp), ("Cout", ci), ("Cin", ci), ("Cp", ci), ("rot", ci)]
 
 
+class CcPackDesc(C.Structure):
+    _fields_ = [("W", vp), ("out", vp), ("Cout", ci), ("Cin", ci), ("mode", ci), ("pad_", ci)]
+
+
 class ConvUnpackDesc(C.Structure):
     _fields_ = [("dWt", vp), ("dW", vp), ("Cout", ci), ("Cin", ci), ("Cp", ci), ("rot", ci), ("accumulate", ci), ("n_major", ci)]
 
@@ -59,6 +63,7 @@ SIGNATURES = {
     "mvit_conv3x3_direct": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_conv3x3_chunked_pack_elems": [ci, ci],
     "mvit_conv3x3_chunked_pack": [vp, vp, ci, ci, ci, vp],
+    "mvit_conv3x3_chunked_pack_multi": [C.POINTER(CcPackDesc), ci, vp],
     "mvit_conv3x3_chunked": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_conv3x3_chunked_wgrad": [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "mvit_pack_conv3x3_direct": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],

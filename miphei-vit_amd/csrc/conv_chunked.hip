@@ -391,9 +391,56 @@ __global__ __launch_bounds__(256) void pack_conv_chunked_kernel(const float* __r
   }
 }
 
+// all chunked operands of a step in ONE launch (blockIdx.y = descriptor): the three forward and three input-gradient operands of the
+// wide fusion blocks used to be six launches and six allocations in the prologue of every training step
+struct CcPackMulti {
+  mvit_cc_pack_desc d[MVIT_CC_PACK_MAX];
+};
+__global__ __launch_bounds__(256) void pack_conv_chunked_multi_kernel(const CcPackMulti pm) {
+  const mvit_cc_pack_desc& d = pm.d[blockIdx.y];
+  const int N = d.mode == 0 ? d.Cout : d.Cin, K = d.mode == 0 ? d.Cin : d.Cout;
+  const int nchunk = (K + CC_CK - 1) / CC_CK, nslice = (N + CC_NS - 1) / CC_NS;
+  const long long total = (long long)nslice * nchunk * 9 * CC_NS * CC_WROW;
+  bf16_t* __restrict__ out = (bf16_t*)d.out;
+  const float* __restrict__ W = d.W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int kl = (int)(i % CC_WROW);
+    long long r = i / CC_WROW;
+    const int nl = (int)(r % CC_NS);
+    r /= CC_NS;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int chunk = (int)(r % nchunk), slice = (int)(r / nchunk);
+    const int n = slice * CC_NS + nl, k = chunk * CC_CK + kl, ky = tap / 3, kx = tap - ky * 3;
+    float v = 0.f;
+    if (kl < CC_CK && n < N && k < K) {
+      if (d.mode == 0) v = W[((size_t)n * d.Cin + k) * 9 + ky * 3 + kx];
+      else v = W[((size_t)k * d.Cin + n) * 9 + (2 - ky) * 3 + (2 - kx)];
+    }
+    out[i] = f2bf(v);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+MVIT_API int mvit_conv3x3_chunked_pack_multi(const mvit_cc_pack_desc* descs, int n, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  if (!descs || n <= 0 || n > MVIT_CC_PACK_MAX) return MVIT_EINVAL;
+  CcPackMulti pm;
+  long long most = 0;
+  for (int i = 0; i < n; ++i) {
+    const mvit_cc_pack_desc& d = descs[i];
+    if (!d.W || !d.out || d.Cout <= 0 || d.Cin <= 0 || (d.mode != 0 && d.mode != 1)) return MVIT_EINVAL;
+    pm.d[i] = d;
+    const long long t = mvit_conv3x3_chunked_pack_elems(d.mode == 0 ? d.Cout : d.Cin, d.mode == 0 ? d.Cin : d.Cout);
+    most = t > most ? t : most;
+  }
+  const long long blocks = (most + 255) / 256;
+  hipLaunchKernelGGL(pack_conv_chunked_multi_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), n), dim3(256), 0, (hipStream_t)stream, pm);
+  return MVIT_LAUNCH_CHECK();
+}
 
 MVIT_API long long mvit_conv3x3_chunked_pack_elems(int N, int K) {
   return (long long)((N + CC_NS - 1) / CC_NS) * ((K + CC_CK - 1) / CC_CK) * 9 * CC_NS * CC_WROW;

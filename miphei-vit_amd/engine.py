@@ -329,7 +329,7 @@ class HipEngine:
         pk.wk, pk.wd, pk.cin, pk.cin_pad, pk.perm = [], [], [], [], []
         pk.wdir_f = pk.wdir_b = None
         pk.wch_f, pk.wch_b = {}, {}          # fusion blocks 0-2: operands of the chunked direct convolution (forward / input gradient)
-        packs = []
+        packs, cpacks = [], []
         for i, cv in enumerate(convs):
             w = f32(cv.conv.weight).contiguous()                                    # [Cout, Cin, 3, 3]
             cout, cin = w.shape[0], w.shape[1]
@@ -340,9 +340,14 @@ class HipEngine:
             if chunked:
                 # wide fusion blocks (1728 -> 256, 352 -> 128, 176 -> 64): direct convolution on LDS-staged tiles, input channels in
                 # chunks of 32, output channels in slices of 64 (csrc/conv_chunked.hip); no implicit-GEMM weight layouts needed
-                pk.wch_f[i] = ops.pack_conv3x3_chunked(w)
-                if need_bwd:
-                    pk.wch_b[i] = ops.pack_conv3x3_chunked(w, dgrad=True)
+                # (packed by ONE launch below, into buffers that persist across steps)
+                bufs = self.__dict__.setdefault("_wch_bufs", {})
+                for dg in ((False, True) if need_bwd else (False,)):
+                    key_ = (i, dg, tuple(w.shape), str(dev))
+                    if key_ not in bufs:
+                        bufs[key_] = torch.empty(ops.conv3x3_chunked_pack_elems(w, dg), device=dev, dtype=bf)
+                    (pk.wch_b if dg else pk.wch_f)[i] = bufs[key_]
+                    cpacks.append((w, bufs[key_], dg))
                 wk = wd = None
             else:
                 wk = torch.empty(cout, 9 * cp, device=dev, dtype=bf)
@@ -361,6 +366,8 @@ class HipEngine:
             pk.cin_pad.append(cp)
             pk.perm.append(perm)
         ops.pack_conv3x3_weights_multi(packs)      # all implicit-GEMM layouts in one launch
+        if cpacks:
+            ops.pack_conv3x3_chunked_multi(cpacks)  # all chunked-kernel operands in one launch (persistent buffers)
         heads = self._heads()
         st = lambda get, shape: torch.stack([f32(get(h)).reshape(-1) for h in heads]).reshape(shape).contiguous()
         NH = c.NH

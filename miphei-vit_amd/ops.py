@@ -434,6 +434,23 @@ def pack_conv3x3_chunked(W, dgrad=False):
     return out
 
 
+def conv3x3_chunked_pack_elems(W, dgrad=False):
+    cout, cin = W.shape[0], W.shape[1]
+    n, k = (cin, cout) if dgrad else (cout, cin)
+    return int(L.lib().mvit_conv3x3_chunked_pack_elems(n, k))
+
+
+def pack_conv3x3_chunked_multi(items):
+    """[(W f32 [Cout,Cin,3,3], out bf16 buffer, dgrad)] -> all operands packed by ONE launch (mvit_conv3x3_chunked_pack_multi)"""
+    n = len(items)
+    arr = (L.CcPackDesc * n)()
+    for i, (W, out, dgrad) in enumerate(items):
+        assert W.dtype == torch.float32 and W.is_contiguous() and out.dtype == torch.bfloat16
+        assert out.numel() >= conv3x3_chunked_pack_elems(W, dgrad)
+        arr[i].W, arr[i].out, arr[i].Cout, arr[i].Cin, arr[i].mode = W.data_ptr(), out.data_ptr(), W.shape[0], W.shape[1], int(dgrad)
+    L.check(L.lib().mvit_conv3x3_chunked_pack_multi(arr, n, _stream()), "mvit_conv3x3_chunked_pack_multi")
+
+
 def conv3x3_chunked(x, wp, y, *, B, H, W, cin, ldx, cout, ldy, stats=None, nslots=0):
     """y[b,h,w,:cout] = conv3x3(x[b,h,w,:cin]) (stride 1, pad 1, NHWC bf16): LDS-staged tiles, 32-channel chunks, 64-channel slices"""
     _chk_bf16(x, "x")
