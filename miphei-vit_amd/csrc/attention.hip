@@ -141,8 +141,19 @@ __device__ __forceinline__ BlockXY block_xy(int nx) {
 }
 
 // ------------------------------------------------------------------ forward
+// -DMVIT_ATTN_TIMING (measurement build, tools/debug/attn_timing.py): s_memtime stamps summed per wave -- [0] launch -> first tile step
+// (descriptor set-up, Q fragments, first DMA), [1] waits at the top of the steps (own DMA + block barrier), [2] the steps' work,
+// [3] epilogue, [4] steps -- written to the `lse` buffer's tail (the caller over-allocates it): 8 longs per wave
+#ifdef MVIT_ATTN_TIMING
+#define ATT_STAMP(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; }
+#else
+#define ATT_STAMP(k)
+#endif
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        bf16_t* __restrict__ out_res, float* __restrict__ lse, AttnDims dm) {
+#ifdef MVIT_ATTN_TIMING
+  long long tsum[5] = {0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -186,8 +197,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
   auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     constexpr bool RAGGED = decltype(ragged_tag)::value;
+    ATT_STAMP(t == 0 ? 0 : 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
+    ATT_STAMP(1)
+#ifdef MVIT_ATTN_TIMING
+    tsum[4] += 1;
+#endif
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
     const char* Ks = smem + SLOT * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
@@ -357,6 +373,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     run(std::false_type{});
   else
     run(std::true_type{});
+  ATT_STAMP(2)
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   {
@@ -380,6 +397,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     if (out_res) store_row_groups(out_res + ro, Dh, half, wr, q < N);
     if (q < N && lse && half == 0) lse[(size_t)bh * N + q] = (m_run + log2f(l_tot)) * LN2;
   }
+#ifdef MVIT_ATTN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_STAMP(3)
+  if (lane == 0) {
+    long long* prof = (long long*)(lse + (size_t)dm.B * dm.H * N) + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int k = 0; k < 5; ++k) prof[k] = tsum[k];
+    prof[5] = (long long)__builtin_readcyclecounter();
+    prof[6] = __builtin_amdgcn_s_getreg((8 << 11) | (0 << 6) | 20) /* XCC_ID */;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ backward, dQ (query-stationary, S^T form)
