@@ -60,7 +60,10 @@ struct TileOrder {   // virtual tile id -> XCD-aware, grouped (8 tile rows x all
   __device__ __forceinline__ void get(int vt, int& m0, int& n0) const {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = vt & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
-    constexpr int GROUP_M = 8;
+#ifndef MVIT_WS_GROUP_M
+#define MVIT_WS_GROUP_M 4
+#endif
+    constexpr int GROUP_M = MVIT_WS_GROUP_M;   // tile rows per group of the walk: an XCD's 32 concurrent tiles are a 4 x 8 patch (4 A panels + 8 B panels per K tile = the least L2-miss bytes); same-box step 482.4 / 481.2 (4) vs 477.7 / 475.4 (8) vs 464.1 / 463.2 (16) tiles/s
     const int per_group = GROUP_M * tiles_n;
     const int first_m = (wg / per_group) * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
