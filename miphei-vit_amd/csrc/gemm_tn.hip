@@ -37,7 +37,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int IT, int JT, int AMODE>
+// TR: the accumulator tiles are computed transposed (MFMA operands swapped), so that the 32 lanes of an output instruction run along i --
+// for outputs whose i index is the contiguous one (ldci == 1: LoRA dA, stored [D][r]) an atomic instruction then touches one or two
+// 128-byte lines instead of 32 (the products are split over m: the atomics are what such a launch waits for)
+template <int IT, int JT, int AMODE, bool TR = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p) {
   constexpr int WI = IT / 32 >= 4 ? 4 : IT / 32;  // waves along i
   constexpr int WJ = 4 / WI;
@@ -139,25 +142,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
         const char* bt = b + (jl / 64) * BLK_BYTES;
         const int b_cb = (jl % 64) + 16 * ((lane >> 4) & 1);
         const bf16x8 fb = join(tr_read4(bt, mb, b_cb, lane), tr_read4(bt, mb + 8, b_cb, lane));
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+        acc[t] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[t], 0, 0, 0)
+                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
       }
     }
     __syncthreads();
     cur ^= 1;
   }
-  // D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*half
+  // D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*half   (TR: col i = lane&31, row j = ...)
   // split_stride > 0: slice zi of the m range adds into its own copy of the output (C + zi * split_stride) -- every element
   // then has exactly one contributing block and the caller sums the copies in a fixed order (run-to-run identical results)
   float* C = (float*)p.C + (size_t)bi * p.strideC + (size_t)zi * p.split_stride;
   float* C2 = p.C2 ? p.C2 + (size_t)bi * p.strideC + (size_t)zi * p.split_stride : nullptr;
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
-    const int j = j0 + wave_j * WJT + t * 32 + l31;
-    if (j >= p.J) continue;
+    const int jb = j0 + wave_j * WJT + t * 32, ib = i0 + il;
+    if (!TR && jb + l31 >= p.J) continue;
+    if (TR && ib + l31 >= p.I) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = i0 + il + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (i >= p.I) continue;
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int i = TR ? ib + l31 : ib + rr;
+      const int j = TR ? jb + rr : jb + l31;
+      if (TR ? j >= p.J : i >= p.I) continue;
       if (!p.C2) {
         atomicAdd(C + (size_t)i * p.ldci + (size_t)j * p.ldcj, acc[t][r]);
       } else if (i < p.isplit) {   // two outputs from one pass (see mvit_gemm_tn_args)
@@ -178,7 +185,13 @@ int launch(const mvit_gemm_tn_args& a, hipStream_t s) {
   if ((long long)split * nb > 65535) return MVIT_EINVAL;
   dim3 grid((a.I + IT - 1) / IT, (a.J + JT - 1) / JT, split * nb);
   const size_t lds = 2 * (size_t)(IT / 64 + (JT + 63) / 64) * BLK_BYTES;
-  if (a.amode == MVIT_A_DENSE)
+#ifndef MVIT_TN_NO_TR
+  if (a.amode == MVIT_A_DENSE && a.ldci == 1 && a.ldcj > 1 && IT == 64 && JT == 128)
+#else
+  if (false)
+#endif
+    hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_DENSE, true>), grid, dim3(256), lds, s, a);
+  else if (a.amode == MVIT_A_DENSE)
     hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_DENSE>), grid, dim3(256), lds, s, a);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_CONV3>), grid, dim3(256), lds, s, a);

@@ -160,28 +160,6 @@ def test_gemm_swiglu_fwd_bwd(M, D, H, Do):
     assert _rel(du.float()[:, idx.argsort()], ref) < 5e-3
 
 
-@pytest.mark.parametrize("nb,msplit", [(3, 1), (5, 4)])
-def test_gemm_tn_batched(nb, msplit):
-    """batch > 1: the LoRA weight gradients of a group of ViT blocks from one launch, both adapters, strided operands/outputs"""
-    ops = _ops()
-    M, r, D = 650, 8, 104
-    t = _rand(nb, M, 2 * r, seed=5).bfloat16()
-    dqkv = _rand(nb, M, 3 * D, seed=6).bfloat16()
-    h = _rand(nb, M, D, seed=7).bfloat16()
-    g = torch.zeros(nb, 4, r * D, device="cuda")          # [block, (Aq, Bq, Av, Bv), r*D] as in the flat gradient buffer
-    ops.gemm_tn(t, dqkv, g[0, 1], M=M, I=2 * r, J=3 * D, lda=2 * r, ldb=3 * D, ldci=D, ldcj=1, msplit=msplit, c2=g[0, 3],
-                isplit=r, j1=D, jlo2=2 * D, batch=nb, stride_a=M * 2 * r, stride_b=M * 3 * D, stride_c=4 * r * D)
-    ops.gemm_tn(t, h, g[0, 0], M=M, I=2 * r, J=D, lda=2 * r, ldb=D, ldci=1, ldcj=r, msplit=msplit, c2=g[0, 2], isplit=r,
-                batch=nb, stride_a=M * 2 * r, stride_b=M * D, stride_c=4 * r * D)
-    for b in range(nb):
-        full = t[b].float().t() @ dqkv[b].float()
-        assert _rel(g[b, 1].view(r, D), full[:r, :D]) < 1e-5 and _rel(g[b, 3].view(r, D), full[r:, 2 * D:]) < 1e-5
-        fa = t[b].float().t() @ h[b].float()
-        assert _rel(g[b, 0].view(D, r), fa[:r].t()) < 1e-5 and _rel(g[b, 2].view(D, r), fa[r:].t()) < 1e-5
-    with pytest.raises(Exception):      # batched products need the dense A mode
-        ops.gemm_tn(t, h, g[0, 0], M=M, I=72, J=32, conv=(5, 5, 8, 8, 5, 5, 1), batch=2)
-
-
 @pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),
                                                  (1, 24, 24, 72, 32, 1), (3, 8, 8, 1728, 256, 1),
                                                  (1, 64, 64, 48, 128, 1), (2, 72, 72, 40, 96, 2),   # 256-row conv tiles
@@ -264,6 +242,23 @@ def test_gemm_tn_batched(nb, msplit):
         assert _rel(g[b, 0].view(D, r), fa[:r].t()) < 1e-5 and _rel(g[b, 2].view(D, r), fa[r:].t()) < 1e-5
     with pytest.raises(Exception):      # batched products need the dense A mode
         ops.gemm_tn(t, h, g[0, 0], M=M, I=72, J=32, conv=(5, 5, 8, 8, 5, 5, 1), batch=2)
+
+
+@pytest.mark.parametrize("M,r,D,nb,msplit", [(5264, 16, 1536, 2, 10), (700, 16, 200, 1, 3), (650, 4, 104, 3, 2)])
+def test_gemm_tn_i_contiguous_outputs(M, r, D, nb, msplit):
+    """ldci == 1 (LoRA dA, stored [D][r]): the accumulator tiles are computed transposed so that an atomic instruction covers whole
+    lines of the output; rank 16 at the training size (both adapters: lanes 0..15 / 16..31 of an instruction go to C / C2), a rank
+    whose 2 r is not 32, a ragged last column block."""
+    ops = _ops()
+    dt = _rand(nb, M, 2 * r, seed=11).bfloat16()
+    h = _rand(nb, M, D, seed=12).bfloat16()
+    g = torch.zeros(nb, 4, r * D, device="cuda")
+    ops.gemm_tn(dt, h, g[0, 0], M=M, I=2 * r, J=D, lda=2 * r, ldb=D, ldci=1, ldcj=r, msplit=msplit, c2=g[0, 2], isplit=r,
+                batch=nb, stride_a=M * 2 * r, stride_b=M * D, stride_c=4 * r * D)
+    for b in range(nb):
+        fa = dt[b].float().t() @ h[b].float()
+        assert _rel(g[b, 0].view(D, r), fa[:r].t()) < 1e-5 and _rel(g[b, 2].view(D, r), fa[r:].t()) < 1e-5
+        assert float(g[b, 1].abs().max()) == 0 and float(g[b, 3].abs().max()) == 0        # nothing written outside the two outputs
 
 
 @pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 16, 16, 8, 48, 2), (1, 32, 32, 48, 96, 2), (2, 16, 16, 352, 128, 1),
