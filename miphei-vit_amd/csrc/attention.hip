@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     constexpr int SLOT = decltype(slot_tag)::value;
     constexpr bool RAGGED = decltype(ragged_tag)::value;
     ATT_STAMP(t == 0 ? 0 : 2)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0) too: s_barrier does not wait for LDS reads in flight, and hipcc sinks the MFMAs that consume the previous tile's last
+    // fragment reads below this barrier (they are not memory operations) -- the reads then cross it unfinished while the other waves
+    // issue the DMA that refills their slot (round 4: one 32-query slab in ~1e4 launches came back with a few stale K / V^T rows)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
     ATT_STAMP(1)
 #ifdef MVIT_ATTN_TIMING
@@ -268,70 +271,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
       }
     l_run += ls2.x + ls2.y;
     // O^T += V^T P^T
-    // Round 4: the sources of an MFMA are never rewritten while it may still be in flight.  The former loop packed P of sub-step s2 + 1
-    // into the registers the MFMA of (s2, dt = 1) had just been issued with (v_cvt_pk_bf16 two instructions behind it) and reloaded
-    // the V^T fragment registers right behind the MFMA reading them; with three waves per SIMD queueing on the matrix pipe that
-    // produced, about once in 10^7 MFMAs, an O with wrong columns 32..63 for one 32-query slab (lse intact) -- run-to-run different
-    // outputs on identical inputs (tools/debug/attn_race.py: 53 of 2000 launches at B = 16, N = 329, H = 24).  Now all four P
-    // operands of the tile are formed first (live together: distinct registers), and the V^T fragments rotate through four buffers,
-    // each reloaded two MFMAs after the one that read it.
-#ifndef MVIT_ATTN_SAFE_PV
-#define MVIT_ATTN_SAFE_PV 1
-#endif
-#if MVIT_ATTN_SAFE_PV
-    {
-      // (measurement variants: 2 = P operands up front, V^T fragment registers reloaded right behind their MFMA as before;
-      //  3 = V^T fragment rotation, P packed per sub-step as before)
-      bf16x8 pb4[4];
-      auto packp = [&](int s2) __attribute__((always_inline)) {
-        float pv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pv[e] = st[s2 >> 1][8 * (s2 & 1) + e];
-        return pack8(pv);
-      };
-      if (MVIT_ATTN_SAFE_PV != 3) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) pb4[s2] = packp(s2);
-      }
-      const int nmm = kt1_live ? 8 : 4;                 // (kt == 1 && !kt1_live: P is exactly 0 there)
-      auto vfrag = [&](int m) __attribute__((always_inline)) {
-        const int s2 = m >> 1, dt = m & 1;
-        const int kbase = 32 * (s2 >> 1) + 16 * (s2 & 1) + 4 * half;
-        const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
-        return join(tr_read4(Vs, kbase, cb, lane), tr_read4(Vs, kbase + 8, cb, lane));
-      };
-      if (MVIT_ATTN_SAFE_PV == 2) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          if (m < nmm) {
-            const bf16x8 a = vfrag(m);
-            oacc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb4[m >> 1], oacc[m & 1], 0, 0, 0);
-          }
-        }
-        asm volatile("" ::"v"(pb4[0]), "v"(pb4[1]), "v"(pb4[2]), "v"(pb4[3]));
-      } else {
-      bf16x8 af[4];
-      af[0] = vfrag(0);
-      af[1] = vfrag(1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        if (m < nmm) {
-          if (MVIT_ATTN_SAFE_PV == 3 && (m & 1) == 0) pb4[m >> 1] = packp(m >> 1);
-          oacc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m & 3], pb4[m >> 1], oacc[m & 1], 0, 0, 0);
-          // keep the sources of MFMA m - 2 allocated until here (an empty statement that names them): hipcc otherwise hands a
-          // register to the next load / pack the moment its last reader has been ISSUED
-          if (m >= 2 && MVIT_ATTN_SAFE_PV == 1) asm volatile("" ::"v"(af[(m - 2) & 3]), "v"(pb4[(m - 2) >> 1]));
-          if (m >= 2 && MVIT_ATTN_SAFE_PV == 3) asm volatile("" ::"v"(af[(m - 2) & 3]));
-          __builtin_amdgcn_sched_barrier(0);
-          if (m + 2 < nmm) af[(m + 2) & 3] = vfrag(m + 2);      // the buffer MFMA m - 2 read: two MFMAs have been issued since
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (MVIT_ATTN_SAFE_PV == 1) asm volatile("" ::"v"(af[2]), "v"(af[3]), "v"(af[0]), "v"(af[1]), "v"(pb4[3]), "v"(pb4[1]));
-      }
-    }
-#else
+    // (Round 4: this loop's V^T fragment reads are the LAST LDS reads of a step.  They used to cross the next step's barrier
+    //  unfinished -- see the wait in front of it -- and about one launch in 40 returned a 32-query slab with wrong columns 32..63.
+    //  Rearranging this loop hid that for a while (the reads happened to complete earlier); the fix is the lgkmcnt(0) at the barrier.)
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
       const int kt = s2 >> 1, h2 = s2 & 1;
@@ -348,7 +290,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[dt], 0, 0, 0);
       }
     }
-#endif
     }
   };
   // full tiles two at a time (compile-time ring slot), then the odd full tile, then the ragged last tile: one straight-line body
@@ -476,7 +417,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
   auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     constexpr bool RAGGED = decltype(ragged_tag)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0) too: s_barrier does not wait for LDS reads in flight, and hipcc sinks the MFMAs that consume the previous tile's last
+    // fragment reads below this barrier (they are not memory operations) -- the reads then cross it unfinished while the other waves
+    // issue the DMA that refills their slot (round 4: one 32-query slab in ~1e4 launches came back with a few stale K / V^T rows)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
     const char* Ks = smem + SLOT * 2 * TILE_BYTES;
@@ -616,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     constexpr bool RAGGED = decltype(ragged_tag)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (lgkmcnt: see the forward kernel's step)
     __builtin_amdgcn_s_barrier();
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
     const char* Qs = smem + SLOT * 2 * TILE_BYTES;

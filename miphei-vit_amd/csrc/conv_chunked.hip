@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void conv3x3_chunked_kernel(const CcArgs p) {
       // the next step: next chunk of this item, or chunk 0 of the block's next item
       const bool last = chunk + 1 == nchunk;
       const int nitem = last ? item + gridDim.x : item, nchk = last ? 0 : chunk + 1;
+      // (lgkmcnt(0): s_barrier does not wait for LDS reads in flight, and the MFMAs consuming the last reads may be scheduled below it;
+      //  the slot is refilled by DMA right behind this barrier -- see attention.hip's step)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                 // every wave has finished reading the slot the next step goes into
       if (nitem < nitems) {
         issue_step(nitem, nchk, buf ^ 1);
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunked_kernel(const CcArgs p) {
         // into this block's slot.  Scratch: the ring slot just consumed (buf ^ 1 after the toggle; `buf` already holds the
         // prefetched first chunk of the next item); the step that refills it is issued behind the next loop barrier.
         float* red = (float*)(Xb + (size_t)(buf ^ 1) * CC_XBUF);    // [4 waves][2][64]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // (all waves are past their last reads of that slot)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv3x3_chunked_wgrad_kernel(const
   int buf = 0;
   for (; t < ntiles; t += p.groups) {
     const int tn = t + p.groups;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (reads of the previous tile finished, not just issued)
     __builtin_amdgcn_s_barrier();
     if (tn < ntiles) {
       issue_tile(tn, buf ^ 1);
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv3x3_chunked_wgrad_kernel(const
     buf ^= 1;
   }
   // the four pixel quarters of an output-channel tile, added in quarter order through LDS (the ring is free now)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   float* red = (float*)smem;                        // [2 channel tiles][9 taps][16 registers][64 lanes]
   for (int qd = 0; qd < 4; ++qd) {

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const CdArgs p) {
   int buf = 0;
   for (; t < ntiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
+    // (lgkmcnt(0): s_barrier does not wait for LDS reads in flight and the MFMAs consuming the last reads may be scheduled below it;
+    //  the buffer is refilled by DMA right behind this barrier -- see attention.hip's step)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // every wave has finished reading the buffer the next tile goes into
     if (tn < ntiles) {
       issue_tile(tn, buf ^ 1);
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const CdArgs p) {
 
   if (p.stats) {
     // sum over the 32 lanes (pixels) of each half, then over the 4 waves through LDS, then one f64 atomic per channel
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     float* red = (float*)Xs;     // [4 waves][2][COUT]
 #pragma unroll
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const CwArgs 
   int buf = 0;
   for (; t < ntiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (reads of the previous tile finished, not just issued)
     __builtin_amdgcn_s_barrier();
     if (tn < ntiles) {
       issue_tile(tn, buf ^ 1);

@@ -688,7 +688,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous step's fragment reads are BACK (its MFMAs may be scheduled below the
+      __builtin_amdgcn_s_barrier();                        //  barrier; s_barrier does not wait for LDS reads): their buffer is refilled next
       if (t + NSTAGE - 1 < t_end) issue_tile(t + NSTAGE - 1, ib);
       const char* a = smem + cb * BUF_BYTES;
       const char* b = a + A_BYTES;
@@ -719,6 +720,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     }
     // every wave is done reading the last K tile: its buffer becomes the epilogue panel, the other NSTAGE-1
     // buffers (starting at cb) receive the first K tiles of the next output tile while the epilogue runs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (reads finished, not just issued: other waves write their panels next)
     __builtin_amdgcn_s_barrier();
     const int last = cb == 0 ? NSTAGE - 1 : cb - 1;
     const int em0 = m0, en0 = n0;

@@ -476,6 +476,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (panel reads finished, not just issued: the producers refill this stage behind B')
     __builtin_amdgcn_s_barrier();                        // B'(unit): the panel stage may be refilled
   };
   int vt = blockIdx.x;

@@ -78,8 +78,10 @@ def test_attention_backward_near_uniform_scores():
 def test_attention_is_run_to_run_identical_at_the_benchmark_shape():
     """B = 16, N = 329, H = 24, Dh = 64 (BASELINE configs[1]): the same launch repeated must give the same bits.  Round 4 found the forward
     kernel returning, in ~2.5 % of launches, one 32-query slab with wrong output columns 32..63 (lse intact; 10-20 % off) -- invisible to
-    tolerance tests over the whole tensor, visible as run-to-run differences (tools/debug/attn_race.py).  400 forward and 200 backward
-    launches: the old kernel fails this with probability 1 - 4e-5."""
+    tolerance tests over the whole tensor, visible as run-to-run differences (tools/debug/attn_race.py): the last fragment reads of a step
+    were still in flight at the next step's s_barrier (attention.hip, the wait in front of it).  400 forward and 200 backward launches: the
+    old forward kernel fails this with probability 1 - 4e-5 (the backward kernels' rate needed the step-level soak of
+    tests/test_deterministic_gpu.py)."""
     import miphei_vit_amd.ops as ops
     B, N, H, Dh = 16, 329, 24, 64
     g = torch.Generator(device="cuda").manual_seed(1)

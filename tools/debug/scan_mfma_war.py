@@ -1,6 +1,7 @@
-"""Scan gfx950 assembly for the hazard found in round 4 (attention forward): a VALU instruction that rewrites a source register (SrcA / SrcB)
-of an MFMA issued a few instructions earlier.  hipcc does not treat it as a hazard; with several waves per SIMD queueing on the matrix pipe
-the MFMA occasionally read the NEW value.  Usage: python tools/debug/scan_mfma_war.py file.s [window]"""
+"""Scan gfx950 assembly for a code shape suspected in round 4 (attention forward): a VALU instruction that rewrites a source register
+(SrcA / SrcB) of an MFMA issued a few instructions earlier.  (NOT the cause in the end -- tools/probes/mfma_war.hip shows the hardware
+interlocks it, and the wrong slabs were LDS reads in flight across s_barrier; kept as a scanner for the pattern.)
+Usage: python tools/debug/scan_mfma_war.py file.s [window]"""
 import re, sys
 
 def regs(tok):
