@@ -17,7 +17,21 @@
 namespace {
 
 typedef short v4s __attribute__((ext_vector_type(4)));
+#ifndef MVIT_ATTN_PK
+#define MVIT_ATTN_PK 1
+#endif
+#if MVIT_ATTN_PK
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+// (measurement build: the same arithmetic on scalar VALU instructions -- compile the unit with -fno-slp-vectorize)
+struct f32x2 {
+  float x, y;
+  __device__ __forceinline__ f32x2& operator+=(const f32x2& o) { x += o.x, y += o.y; return *this; }
+};
+__device__ __forceinline__ f32x2 operator*(const f32x2& a, const f32x2& b) { return {a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int KVB = 64;          // keys per LDS tile
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const f32x2 x = __builtin_elementwise_fma((f32x2){st[kt][r], st[kt][r + 1]}, sc2, nm2);
+        const f32x2 x = fma2((f32x2){st[kt][r], st[kt][r + 1]}, sc2, nm2);
         const f32x2 p2 = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
         st[kt][r] = p2.x;
         st[kt][r + 1] = p2.y;
@@ -448,10 +462,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const f32x2 x = __builtin_elementwise_fma((f32x2){st[r], st[r + 1]}, sc2, nL2);
+          const f32x2 x = fma2((f32x2){st[r], st[r + 1]}, sc2, nL2);
           f32x2 p2 = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
           if (RAGGED) p2 = {key < N ? p2.x : 0.f, key + 1 < N ? p2.y : 0.f};
-          const f32x2 ds2 = p2 * __builtin_elementwise_fma((f32x2){dp[r], dp[r + 1]}, s2, nD2);
+          const f32x2 ds2 = p2 * fma2((f32x2){dp[r], dp[r + 1]}, s2, nD2);
           st[r] = ds2.x;
           st[r + 1] = ds2.y;
         }
@@ -592,10 +606,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {   // two query rows per packed VALU instruction
             const int r = 4 * g + e;
-            const f32x2 x = __builtin_elementwise_fma((f32x2){st[r], st[r + 1]}, (f32x2){sc, sc}, (f32x2){-Lv[e], -Lv[e + 1]});
+            const f32x2 x = fma2((f32x2){st[r], st[r + 1]}, (f32x2){sc, sc}, (f32x2){-Lv[e], -Lv[e + 1]});
             f32x2 p2 = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
             if (RAGGED) p2 = {qt0 + qb4 + e < N ? p2.x : 0.f, qt0 + qb4 + e + 1 < N ? p2.y : 0.f};
-            const f32x2 ds2 = p2 * __builtin_elementwise_fma((f32x2){dp[r], dp[r + 1]}, (f32x2){dm.scale, dm.scale},
+            const f32x2 ds2 = p2 * fma2((f32x2){dp[r], dp[r + 1]}, (f32x2){dm.scale, dm.scale},
                                                               (f32x2){-Dv_[e], -Dv_[e + 1]});   // (D is stored scaled)
             st[r] = p2.x, st[r + 1] = p2.y;        // P
             dp[r] = ds2.x, dp[r + 1] = ds2.y;      // dS
