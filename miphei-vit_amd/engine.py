@@ -747,8 +747,12 @@ class HipEngine:
         if not sv.bn_train:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the training path")
         c, fz, fl = self._config(), self._ensure_frozen_bwd(), self._ensure_flat()
-        if not c.lora:
-            raise NotImplementedError("training a fully unfrozen encoder is outside the MIPHEI-ViT (LoRA) hot path")
+        if not c.lora and any(p.requires_grad for p in self.model.encoder.vit.parameters()):
+            # get_vitmatte(use_lora=False) leaves every encoder weight trainable (reference mipheivit.py:224-231: full fine-tuning with
+            # layer-wise lr decay, models.py:347-357); that needs the weight gradients of 1.1 G frozen-layout parameters and is outside the
+            # LoRA hot path.  With the encoder frozen (requires_grad_(False) on generator.encoder) the decoder trains on fixed features.
+            raise NotImplementedError("training a fully unfrozen encoder is outside the MIPHEI-ViT (LoRA) hot path: freeze it "
+                                      "(model.encoder.requires_grad_(False): decoder-only training) or build with use_lora=True")
         w, pk, convs = sv.w, sv.pk, sv.convs
         B, D, M = w.B, c.D, w.M
         S, s1, s2, s3, G = w.res
@@ -838,8 +842,10 @@ class HipEngine:
                                         for i, cv in enumerate(convs)])
         if on_decoder_done is not None:
             on_decoder_done()
-        # ---- encoder (LoRA gradients; frozen weights need dgrad only)
-        self._encoder_bwd(w, pk, fl, fz, on_block_done=on_lora_block_done)
+        # ---- encoder (LoRA gradients; frozen weights need dgrad only).  No adapters = a frozen encoder (checked above): nothing upstream
+        # of the decoder has a gradient
+        if c.lora:
+            self._encoder_bwd(w, pk, fl, fz, on_block_done=on_lora_block_done)
         return fl.gflat
 
     def lora_blocks(self):

@@ -214,3 +214,45 @@ def test_edge_shapes_forward_backward(cfgname, img, nc, B):
             # bf16 autocast mode - see test_backward_matches_oracle_autograd for the yardstick); heads are shallow
             tol = 0.1 if k.startswith("decoder.segmentation_head") else 0.35
             assert _rel(got, gr) < tol, (k, _rel(got, gr))
+
+
+def test_decoder_only_training_with_a_frozen_encoder():
+    """get_vitmatte(use_lora=False): the reference then fine-tunes the whole encoder (outside the LoRA hot path: refused with a message that
+    says what to do); with the encoder frozen the decoder trains on fixed features -- its gradients must equal those of the LoRA model whose
+    adapters are still at their initial B = 0 (same forward), and one optimiser step must move the decoder only."""
+    from oracle import synth_batch
+    from oracle.model import orion_marker_weights
+    from miphei_vit_amd.generators import get_vitmatte
+    from miphei_vit_amd.loss import WeightedMSELoss
+    from miphei_vit_amd.models import ModelModule
+    cfgname, img, nc, B = "tiny_swiglu", 128, 16, 3
+    cfg, p, lora_model = _load(cfgname, img, nc, seed=4)
+    for k, v in lora_model.named_parameters():                 # adapters at their initial state: B = 0 -> no contribution to the forward
+        if ".lora_" in k and k.endswith(".B"):
+            v.data.zero_()
+    plain = get_vitmatte(cfgname, img, nc, use_lora=False, pretrained=False)
+    sd = {k.replace(".qkv.qkv.", ".qkv."): v for k, v in lora_model.state_dict().items() if ".lora_" not in k}
+    plain.load_state_dict(sd)
+    plain.cuda()
+    x, y = synth_batch(11, B, img, nc)
+    batch = {"image": x.cuda(), "target": y.cuda()}
+    mk = lambda m: ModelModule(m, None, 1e-3, 0., WeightedMSELoss(50.0, orion_marker_weights(nc)))
+    mod_p = mk(plain)
+    with pytest.raises(NotImplementedError, match="freeze"):
+        mod_p.training_step(batch, 0)                          # every encoder weight trainable: full fine-tuning is refused
+    plain.encoder.requires_grad_(False)
+    dec0 = {k: v.detach().clone() for k, v in plain.decoder.named_parameters()}
+    enc0 = {k: v.detach().clone() for k, v in plain.encoder.named_parameters()}
+    mod_p.total_iters, mod_p.global_step_ = 4000, 1000
+    loss_p = float(mod_p.training_step(batch, 0))
+    mod_l = mk(lora_model)
+    mod_l.total_iters, mod_l.global_step_ = 4000, 1000
+    loss_l = float(mod_l.training_step(batch, 0))
+    assert abs(loss_p - loss_l) < 1e-4 * abs(loss_l)
+    gl = dict(lora_model.decoder.named_parameters())
+    for k, v in plain.decoder.named_parameters():
+        assert v.grad is not None and _rel(v.grad, gl[k].grad) < 1e-3, k
+        if float(gl[k].grad.abs().max()) > 1e-12:               # (a bias in front of a BatchNorm has no gradient)
+            assert not torch.equal(v.detach(), dec0[k]), k      # the step moved it
+    for k, v in plain.encoder.named_parameters():
+        assert torch.equal(v.detach(), enc0[k]), k

@@ -33,9 +33,14 @@ python3 tools/bench_vs_blas.py > $O/gemm_vs_hipblaslt.txt 2>/dev/null
 { python3 tools/bench_attn.py 329 ours; python3 tools/bench_attn.py 1301 ours; } > $O/attn.txt 2>/dev/null
 python3 tools/bench_decoder_convs.py > $O/decoder_convs.txt 2>/dev/null
 python3 tools/bench_small.py > $O/small_kernels.txt 2>/dev/null
+python3 tools/bench_lora_wgrad.py > $O/lora_wgrad.txt 2>/dev/null
+# run-to-run identity of the whole step (deterministic mode, 1000 repeats of forward + loss + backward on one input, bitwise) and of the
+# hipGraph-free inference forward at batch 64
+{ MIPHEI_DETERMINISTIC=1 python3 tools/debug/step_soak.py 1000 16 256 myvitmatte train 2>/dev/null | tail -2
+  MIPHEI_DETERMINISTIC=1 python3 tools/debug/step_soak.py 500 64 256 myvitmatte infer 2>/dev/null | tail -1; } > $O/step_soak.txt
 if [ "${COPY:-1}" = 1 ]; then
   for f in $O/bench_*.json $O/kernel_stats_train.txt $O/pmc_traffic.json $O/step_counters.txt $O/gemm_sq_counters.txt $O/gemm_epilogues.txt \
-           $O/gemm_vs_hipblaslt.txt $O/attn.txt $O/decoder_convs.txt $O/small_kernels.txt; do
+           $O/gemm_vs_hipblaslt.txt $O/attn.txt $O/decoder_convs.txt $O/small_kernels.txt $O/lora_wgrad.txt $O/step_soak.txt; do
     [ -s "$f" ] && cp $f profiles/${R}_$(basename $f)
   done
 fi
