@@ -3,7 +3,9 @@ tolerance test sees).  MIPHEI_DETERMINISTIC=1: forward + loss + backward of the 
 times on ONE input with unchanged weights; the output tensor and the flat gradient buffer of every repeat are compared bit for bit with
 the first.  Prints the number of differing repeats (and, for the first one, which slices of the gradient buffer differ).
   MIPHEI_DETERMINISTIC=1 python tools/debug/step_soak.py [N=30] [B=16] [img=256] [generator=myvitmatte|unet_lora] [mode=train|infer]
-(infer: the eval-mode forward alone -- the kernels' inference variants: no saved pre-activations, no attention residual)"""
+(infer: the eval-mode forward alone -- the kernels' inference variants: no saved pre-activations, no attention residual)
+Environment: SOAK_ENCODER=tiny_swiglu|tiny4_swiglu|... (oracle.VIT_CONFIGS name, default hoptimus0), SOAK_CHUNKED=0 (fusion convolutions on the
+implicit GEMM), SOAK_ATTN_RES=0 (no rounding residual of O)."""
 import hashlib, os, sys
 os.environ.setdefault("MIPHEI_DETERMINISTIC", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,14 +30,17 @@ assert ops.DETERMINISTIC, "run with MIPHEI_DETERMINISTIC=1"
 with torch.device(dev):
     if gen == "unet_lora":
         from miphei_vit_amd.generators.unet import Unet
-        model = Unet(img, "hoptimus0", use_lora=True, classes=nc, pretrained=False)
+        model = Unet(img, os.environ.get("SOAK_ENCODER", "hoptimus0"), use_lora=True, classes=nc, pretrained=False)
     else:
-        model = get_vitmatte("hoptimus0", img, nc, use_lora=True, pretrained=False)
+        model = get_vitmatte(os.environ.get("SOAK_ENCODER", "hoptimus0"), img, nc, use_lora=True, pretrained=False)
 bench.synthetic_init_(model, seed=13)
 model.to(dev).train()
 if len(sys.argv) > 5 and sys.argv[5] == "infer":
     model.eval()
 eng = model._engine
+if hasattr(eng, "use_chunked_conv"):
+    eng.use_chunked_conv = os.environ.get("SOAK_CHUNKED", "1") == "1"
+    eng.attn_residual = os.environ.get("SOAK_ATTN_RES", "1") == "1"
 loss_fn = WeightedMSELoss(50.0, orion_marker_weights(nc)).to(dev)
 x, y = bench.synthetic_batch(300, B, img, nc, dev)
 
