@@ -40,7 +40,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr) {
 // TR: the accumulator tiles are computed transposed (MFMA operands swapped), so that the 32 lanes of an output instruction run along i --
 // for outputs whose i index is the contiguous one (ldci == 1: LoRA dA, stored [D][r]) an atomic instruction then touches one or two
 // 128-byte lines instead of 32 (the products are split over m: the atomics are what such a launch waits for)
-template <int IT, int JT, int AMODE, bool TR = false>
+// NST: LDS stages.  2 = one step of DMA in flight per block, three blocks per CU.  3 (-DMVIT_TN_STAGES=3, batched LoRA launches only) keeps two
+// steps in flight but only two blocks per CU fit: measured SLOWER (dB 68 -> 74 us, dA 51 -> 57 us per launch of 10 blocks), kept at 2
+template <int IT, int JT, int AMODE, bool TR = false, int NST = 2>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p) {
   constexpr int WI = IT / 32 >= 4 ? 4 : IT / 32;  // waves along i
   constexpr int WJ = 4 / WI;
@@ -125,11 +127,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
   const char* const a_off = (const char*)0 + (il / 64) * BLK_BYTES;
   const int a_cb = (il % 64) + 16 * ((lane >> 4) & 1);
 
-  issue(s_begin, 0);
-  __syncthreads();
+  // Stage st + NST - 1 is requested at the top of step st (behind the barrier that says every wave is done with the stage it
+  // overwrites); a step waits for its own stage with a counted vmcnt -- the younger stages stay in flight -- and for this wave's LDS
+  // reads of the previous step (lgkmcnt: s_barrier does not), then meets the other waves.
+  constexpr int DMAS = 2 * (ABLK + BBLK);              // DMA instructions per wave and stage
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (s_begin + i < s_end) issue(s_begin + i, i);
   int cur = 0;
   for (long long st = s_begin; st < s_end; ++st) {
-    if (st + 1 < s_end) issue(st + 1, cur ^ 1);
+    if (NST == 3 && st + 1 < s_end)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMAS) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + NST - 1 < s_end) issue(st + NST - 1, cur == 0 ? NST - 1 : cur - 1);
     const char* a = smem + cur * STAGE + (size_t)a_off;
     const char* b = smem + cur * STAGE + ABLK * BLK_BYTES;
 #pragma unroll
@@ -146,8 +158,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
       }
     }
-    __syncthreads();
-    cur ^= 1;
+    cur = cur + 1 == NST ? 0 : cur + 1;
   }
   // D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*half   (TR: col i = lane&31, row j = ...)
   // split_stride > 0: slice zi of the m range adds into its own copy of the output (C + zi * split_stride) -- every element
@@ -184,17 +195,33 @@ int launch(const mvit_gemm_tn_args& a, hipStream_t s) {
   const int nb = a.batch > 1 ? a.batch : 1;
   if ((long long)split * nb > 65535) return MVIT_EINVAL;
   dim3 grid((a.I + IT - 1) / IT, (a.J + JT - 1) / JT, split * nb);
-  const size_t lds = 2 * (size_t)(IT / 64 + (JT + 63) / 64) * BLK_BYTES;
-#ifndef MVIT_TN_NO_TR
-  if (a.amode == MVIT_A_DENSE && a.ldci == 1 && a.ldcj > 1 && IT == 64 && JT == 128)
-#else
-  if (false)
+  const size_t lds2 = 2 * (size_t)(IT / 64 + (JT + 63) / 64) * BLK_BYTES;
+  int rc = MVIT_OK;
+  auto go = [&](auto kern, size_t lds, mvit_per_device_size& raised) {
+    rc = mvit_ensure_dynamic_lds((const void*)kern, lds, raised);
+    if (rc == MVIT_OK) hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  };
+#ifndef MVIT_TN_STAGES
+#define MVIT_TN_STAGES 2
 #endif
-    hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_DENSE, true>), grid, dim3(256), lds, s, a);
-  else if (a.amode == MVIT_A_DENSE)
-    hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_DENSE>), grid, dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL((gemm_tn_kernel<IT, JT, MVIT_A_CONV3>), grid, dim3(256), lds, s, a);
+  constexpr int NSL = (IT == 64 && JT == 128) ? MVIT_TN_STAGES : 2;     // stages of the batched LoRA launches
+  if (a.amode == MVIT_A_DENSE && a.batch > 1 && NSL == 3) {
+    static mvit_per_device_size r0, r1;                 // (per kernel: the attribute belongs to the function)
+    if (a.ldci == 1 && a.ldcj > 1)
+      go(gemm_tn_kernel<IT, JT, MVIT_A_DENSE, true, NSL>, lds2 / 2 * 3, r0);
+    else
+      go(gemm_tn_kernel<IT, JT, MVIT_A_DENSE, false, NSL>, lds2 / 2 * 3, r1);
+  } else if (a.amode == MVIT_A_DENSE && a.ldci == 1 && a.ldcj > 1 && IT == 64 && JT == 128) {
+    static mvit_per_device_size r2;
+    go(gemm_tn_kernel<IT, JT, MVIT_A_DENSE, true>, lds2, r2);
+  } else if (a.amode == MVIT_A_DENSE) {
+    static mvit_per_device_size r3;
+    go(gemm_tn_kernel<IT, JT, MVIT_A_DENSE>, lds2, r3);
+  } else {
+    static mvit_per_device_size r4;
+    go(gemm_tn_kernel<IT, JT, MVIT_A_CONV3>, lds2, r4);
+  }
+  if (rc != MVIT_OK) return rc;
   return MVIT_LAUNCH_CHECK();
 }
 
