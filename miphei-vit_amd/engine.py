@@ -887,14 +887,16 @@ class HipEngine:
                 # LoRA weight gradients of blocks l .. l+G-1 on the TN MFMA GEMM, both adapters per pass and the whole group
                 # per launch: dB = t^T [dq | . | dv] (rows of B_q from the q columns, rows of B_v from the v columns),
                 # dA = ([dt_q | dt_v]^T h)^T (columns of A_q, A_v).  One block's products are 4 steps of m per workgroup -
-                # latency-bound at 13 us each; a group of 10 streams its operands at the fabric rate.
+                # latency-bound at 13 us each; a group of 10 streams its operands at the fabric rate.  dA's slices: one round of
+                # blocks (3 per CU x 256 CUs; 12 column tiles x 10 blocks x 6 slices = 720: 41.7 us against 49.9 with 10 slices).
                 n = min(G, c.L - l)
                 gsplit = max(1, min(lsplit, -(-1024 // (n * 2 * ((D + 127) // 128)))))
                 ops.gemm_tn(w.t[l], dqkv, fl.dBq[l], M=M, I=2 * r_, J=3 * D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1,
                             msplit=gsplit, c2=fl.dBv[l], isplit=r_, j1=D, jlo2=2 * D, batch=n, stride_a=M * 2 * r_,
                             stride_b=M * 3 * D, stride_c=4 * r_ * D)
                 ops.gemm_tn(dt, w.h1[l], fl.dAq[l], M=M, I=2 * r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_,
-                            msplit=max(1, min(lsplit, 2 * gsplit)), c2=fl.dAv[l], isplit=r_, batch=n, stride_a=M * 2 * r_,
+                            msplit=max(1, min(lsplit, 768 // (n * ((D + 127) // 128)))), c2=fl.dAv[l], isplit=r_, batch=n,
+                            stride_a=M * 2 * r_,
                             stride_b=M * D, stride_c=4 * r_ * D)
                 for j in range(l + n - 1, l - 1, -1):
                     if c.alpha != 1.0:   # B2 carries alpha*B: d(B) = alpha * d(alpha*B); scaled before the slice may be exchanged
