@@ -732,7 +732,7 @@ class HipEngine:
         K9 = 9 * cin_pad
         it, jt = (128, 32) if cout <= 32 else (64, 128)
         tiles = ((K9 + it - 1) // it) * ((cout + jt - 1) // jt)
-        ms = max(1, min(1024 // tiles, (Mo + 255) // 256))
+        ms = max(1, min(768 // tiles, (Mo + 255) // 256))     # one round of blocks (3 per CU): 105 us for the three ConvStream layers, 124 at 1024
         ops.gemm_tn(src, dpre, w.dWt[i], M=Mo, I=K9, J=cout, ldb=cout, ldci=cout, msplit=ms,
                     conv=(r_in, r_in, cin_pad, ld, r_out, r_out, stride))
 

@@ -49,7 +49,7 @@ for name, r_in, cp, r_out, cout, stride in layers:
     K9 = 9 * cp
     it_, jt = (128, 32) if cout <= 32 else (64, 128)
     tiles = ((K9 + it_ - 1) // it_) * ((cout + jt - 1) // jt)
-    ms = max(1, min(1024 // tiles, (Mo + 255) // 256))
+    ms = max(1, min(int(os.environ.get("WG_SLOTS", "768")) // tiles, (Mo + 255) // 256))      # (WG_SLOTS: scan of the block budget)
     dwt = torch.zeros(K9, cout, device="cuda")
     t_w = timeit(lambda: ops.gemm_tn(x, dy, dwt, M=Mo, I=K9, J=cout, ldb=cout, ldci=cout, msplit=ms, conv=(r_in, r_in, cp, cp, r_out, r_out, stride)))
     line = (f"{name}: {gf:6.1f} GF | fwd {t_f:7.1f} us {gf / t_f:5.2f} PF | dgrad {t_d:7.1f} us {gf / t_d:5.2f} PF | "
