@@ -268,22 +268,27 @@ def main(argv=None):
     # roofline leg: HIP events around the launches of the dominant kernel, on a SAMPLE of the timed steps (every probe_every-th,
     # at least one): an event pair costs the stream ~6 us of idle time per launch, which on all 159 launches of every step was
     # 2.9 % of the headline number (395 vs 406.5 tiles/s same box)
-    # Round 4: the probe samples ONE of the timed steps (the middle one: 159 launches of the dominant kernel), and one event per
+    # Round 4: the probe samples ONE of the timed steps (the middle one) and every fourth of its 159 launches of the dominant kernel
+    # (qkv forward x 40, then the dfc1 / dproj / dqkv input gradients in turn: a stride of 4 keeps the four shapes' proportions), and one event per
     # step boundary (a marker every ~35 ms) gives the duration of every step, so the line also carries the rate of the unprobed
     # steps (`unprobed`).  Measured per step (`unprobed.step_ms`): a probed step in the middle of the run costs +1.0 ms, the FIRST
     # timed step +2.6 ms when probed (the host is not yet ahead of the device there and pays 318 event creations on the critical
     # path): five sampled steps of 20 cost the headline ~0.7 %, steps {0, K/2} 0.5 %, the middle step alone 0.15 %.
     ops.PROBE.start()
-    ops.PROBE.on = False
+    ops.PROBE.stride = 4      # every fourth launch of the sampled step (40 of 159: the four shapes in their proportions): the probed step
+    ops.PROBE.on = False      # then costs ~0.25 ms instead of ~1 ms
     probed = [a.steps // 2] if a.probe else []
     probe_every = max(1, a.steps // 2)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    host_ms = []
     for i in range(a.steps):
         ops.PROBE.on = i in probed
+        th = time.perf_counter()
         step(a.warmup + i)
         marks[i + 1].record()
+        host_ms.append((time.perf_counter() - th) * 1e3)      # host time to enqueue the step (the device runs behind)
     ops.PROBE.on = True
     torch.cuda.synchronize()
     if world > 1:
@@ -329,6 +334,7 @@ def main(argv=None):
     }
     res["unprobed"] = {"ms_per_step": round(sum(free_ms) / len(free_ms), 3), "tiles_per_s": round(a.batch * world * len(free_ms) / (sum(free_ms) * 1e-3), 2),
                        "steps": len(free_ms), "probed_steps": len(probed), "step_ms": [round(t, 2) for t in step_ms],
+                       "host_enqueue_ms": [round(t, 2) for t in host_ms],
                        "note": "this rank's timed steps that carried no HIP-event probe (step-boundary events on the compute stream); "
                                "`value` is the contract number over ALL timed steps, probe overhead included"}
     if dist.is_initialized():
@@ -364,10 +370,12 @@ def main(argv=None):
             res["roofline"] = {"bound": "mfma", "kernel": dom,
                                "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16, 4), "traffic": traffic, "traffic_source": src,
-                               "launches": probe["n"], "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2),
+                               "launches": probe["seen"], "sampled_launches": probe["n"],
+                               "avg_launch_us": round(probe["ms"] * 1e3 / probe["n"], 2),
                                "sampled_steps": len(probed),
                                "peak_sustained": SUSTAINED_BF16 / 1e12, "frac_of_sustained": round(ach / SUSTAINED_BF16, 4),
-                               "note": "HIP events on the stream around every launch of this kernel in the sampled timed steps"}
+                               "note": "HIP events on the stream around every fourth launch of this kernel (`sampled_launches` of `launches`: its four "
+                                       "shapes in their proportions) in the sampled timed step"}
         if kernels:
             tot_ms = sum(v["ms"] for v in kernels.values())
             rk = []

@@ -27,15 +27,17 @@ class _Probe:
         self.on = False
         self.events = []
         self.ws = False        # the sampled launches ran the wave-specialised kernel
+        self.stride = 1        # time every stride-th eligible launch (bench.py: 4 -- the launches cycle through their four shapes with
+        self.seen = 0          # periods 1 and 3, so every fourth one is a balanced sample); `seen` counts the eligible launches
 
     def start(self):
-        self.on, self.events = True, []
+        self.on, self.events, self.seen = True, [], 0
 
     def stop(self):
         self.on = False
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
-        return {"n": len(self.events), "ms": ms, "flops": float(sum(f for _, _, f in self.events))}
+        return {"n": len(self.events), "seen": self.seen, "ms": ms, "flops": float(sum(f for _, _, f in self.events))}
 
 
 class _KernelProbe:
@@ -133,6 +135,9 @@ def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=No
     # (gemm_kernel<256,128,4,2,DENSE,STORE>: the dgrad GEMMs and the plain-store forward ones), as reported by the library's own dispatcher
     probe = (PROBE.on and amode == A_DENSE and epi == EPI_STORE and ksplit == 1
              and (L.lib().mvit_gemm_variant(C.byref(g)) & ~WS_BIT) == PROBE_VARIANT)
+    if probe:
+        PROBE.seen += 1
+        probe = PROBE.seen % PROBE.stride == 0
     kprobe = KPROBE.on and amode == A_DENSE and ksplit == 1
     if probe or kprobe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
