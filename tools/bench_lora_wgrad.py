@@ -34,7 +34,9 @@ h1 = [torch.randn(n, M, D, device="cuda").to(bf) for _ in range(NG)]
 dBq, dBv, dAq, dAv = (torch.zeros(n, 4 * r * D, device="cuda") for _ in range(4))
 lsplit = max(1, min(512 // ((D + 127) // 128), (M + 255) // 256))
 gs0 = max(1, min(lsplit, -(-1024 // (n * 2 * ((D + 127) // 128)))))
-splits = [int(v) for v in sys.argv[1:]] or [gs0]
+ga0 = max(1, min(lsplit, 768 // (n * ((D + 127) // 128))))           # the engine's slice count of the dA launch
+scan = [int(v) for v in sys.argv[1:]]
+splits = scan or [gs0]
 k = [0]
 
 
@@ -53,6 +55,6 @@ def dA(ms):
 for ms in splits:
     u = timeit(lambda: dB(ms))
     print(f"dB  msplit {ms:3d}: {u:7.1f} us  {n * M * 2 * D * 2 / u / 1e6:5.2f} TB/s")
-for ms in splits:
-    u = timeit(lambda: dA(2 * ms))
-    print(f"dA  msplit {2 * ms:3d}: {u:7.1f} us  {n * M * D * 2 / u / 1e6:5.2f} TB/s")
+for ms in ([2 * v for v in scan] or [ga0]):
+    u = timeit(lambda: dA(ms))
+    print(f"dA  msplit {ms:3d}: {u:7.1f} us  {n * M * D * 2 / u / 1e6:5.2f} TB/s")
