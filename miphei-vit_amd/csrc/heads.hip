@@ -437,7 +437,10 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const bf16_t* __restrict_
         float y0 = bias[0], y1 = bias[1], y2 = bias[2], y3 = bias[3];
 #pragma unroll
         for (int d = 0; d < 9; ++d) {
-          const float4 a = *(const float4*)(Ps + (size_t)((oy + d / 3) * CF_RW + ox + d % 3) * CF_PS + d * 64 + hq * 16);
+          // (a 4-float VECTOR type: through HIP's float4 struct hipcc scalarised this read into ds_read2_b32 + 2 ds_read_b32, whose
+          //  4-byte lanes at a 592-byte stride are 4-way bank conflicts -- 45 % of the kernel's LDS cycles in round 3's counters)
+          typedef float f32x4_lds __attribute__((ext_vector_type(4)));
+          const f32x4_lds a = *(const f32x4_lds*)(Ps + (size_t)((oy + d / 3) * CF_RW + ox + d % 3) * CF_PS + d * 64 + hq * 16);
           y0 += a.x, y1 += a.y, y2 += a.z, y3 += a.w;
         }
         const size_t plane = (size_t)H * W;

@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from miphei_vit_amd import _lib
+if os.environ.get("MIPHEI_LIB"):                      # a variant / older build of the library for same-box comparisons
+    _lib.LIB_PATH = os.path.abspath(os.environ["MIPHEI_LIB"])
 import miphei_vit_amd.ops as ops
 
 B, H, W, NH = 16, 256, 256, 16
