@@ -54,7 +54,10 @@ class HipEngine:
         self._flat = None
         self._opt_stash = None       # Adam state carried across re-flattening (see invalidate)
         self._nonfinite = None       # device int32: sticky NaN-guard flag written by the Adam kernel
-        self.lora_group = 10         # ViT blocks whose LoRA weight-gradient products share one launch (_encoder_bwd)
+        self.lora_group = None       # ViT blocks whose LoRA weight-gradient products share one launch (_encoder_bwd).  None = automatic:
+        #                              10 when a gradient exchange consumes the blocks group by group (on_lora_block_done), otherwise all
+        #                              blocks in one pair of launches (385 us against 436 us for four groups of 10 at the benchmark shape,
+        #                              +0.3 % on the step)
         self.use_chunked_conv = True  # fusion blocks 0-2 on the chunked direct convolution (False: implicit GEMM, for A/B runs)
         self.attn_residual = True     # keep the bf16 rounding residual of the attention output for the backward's D term (A/B switch)
         self.invalidate()
@@ -861,7 +864,10 @@ class HipEngine:
         r_ = c.rank
         scale = c.Dh ** -0.5
         lsplit = max(1, min(512 // ((D + 127) // 128), (M + 255) // 256))
-        G = max(1, int(self.lora_group))
+        if self.lora_group is None:
+            G = c.L if on_block_done is None else 10
+        else:
+            G = max(1, int(self.lora_group))
         last = fz.blocks[c.L - 1]
         dp = getattr(w, "dpath", None)          # DropPath factors of the forward pass this backward belongs to
         rs = (lambda l, br: None) if dp is None else (lambda l, br: dp[l, br])
@@ -888,14 +894,15 @@ class HipEngine:
                 # per launch: dB = t^T [dq | . | dv] (rows of B_q from the q columns, rows of B_v from the v columns),
                 # dA = ([dt_q | dt_v]^T h)^T (columns of A_q, A_v).  One block's products are 4 steps of m per workgroup -
                 # latency-bound at 13 us each; a group of 10 streams its operands at the fabric rate.  dA's slices: one round of
-                # blocks (3 per CU x 256 CUs; 12 column tiles x 10 blocks x 6 slices = 720: 41.7 us against 49.9 with 10 slices).
+                # blocks (3 per CU x 256 CUs; 12 column tiles x 10 blocks x 6 slices = 720: 41.7 us against 49.9 with 10 slices); groups of
+                # more than 16 blocks: 4 slices (40 blocks: 138.8 us; 152.1 / 141.7 / 153.9 with 2 / 6 / 8).
                 n = min(G, c.L - l)
                 gsplit = max(1, min(lsplit, -(-1024 // (n * 2 * ((D + 127) // 128)))))
                 ops.gemm_tn(w.t[l], dqkv, fl.dBq[l], M=M, I=2 * r_, J=3 * D, lda=2 * r_, ldb=3 * D, ldci=D, ldcj=1,
                             msplit=gsplit, c2=fl.dBv[l], isplit=r_, j1=D, jlo2=2 * D, batch=n, stride_a=M * 2 * r_,
                             stride_b=M * 3 * D, stride_c=4 * r_ * D)
                 ops.gemm_tn(dt, w.h1[l], fl.dAq[l], M=M, I=2 * r_, J=D, lda=2 * r_, ldb=D, ldci=1, ldcj=r_,
-                            msplit=max(1, min(lsplit, 768 // (n * ((D + 127) // 128)))), c2=fl.dAv[l], isplit=r_, batch=n,
+                            msplit=max(1, min(lsplit, 768 // (n * ((D + 127) // 128)) if n <= 16 else 4)), c2=fl.dAv[l], isplit=r_, batch=n,
                             stride_a=M * 2 * r_,
                             stride_b=M * D, stride_c=4 * r_ * D)
                 for j in range(l + n - 1, l - 1, -1):

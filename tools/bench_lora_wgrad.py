@@ -10,7 +10,7 @@ if os.environ.get("MIPHEI_LIB"):
 import miphei_vit_amd.ops as ops
 
 bf = torch.bfloat16
-M, D, r, n = 16 * 329, 1536, int(os.environ.get("LORA_RANK", "8")), 10      # rank 8 = the training configuration
+M, D, r, n = 16 * 329, 1536, int(os.environ.get("LORA_RANK", "8")), int(os.environ.get("LORA_GROUP", "10"))   # rank 8, 10 blocks per launch = the training configuration
 
 
 def timeit(fn, it=20):
@@ -27,7 +27,7 @@ def timeit(fn, it=20):
 
 
 # 4 groups of operands so that consecutive launches do not find their operands in the Infinity Cache (as in the step)
-NG = 4
+NG = 4 if n <= 10 else 2
 t = [torch.randn(n, M, 2 * r, device="cuda").to(bf) for _ in range(NG)]
 dqkv = [torch.randn(n, M, 3 * D, device="cuda").to(bf) for _ in range(NG)]
 h1 = [torch.randn(n, M, D, device="cuda").to(bf) for _ in range(NG)]
