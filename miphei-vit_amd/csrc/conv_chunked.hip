@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunked_kernel(const CcArgs p) {
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();                 // ... and so have the other waves' pieces
+      __builtin_amdgcn_s_barrier();                 // ... and so have the other waves' pieces [no LDS reads pending]: none issued since the barrier above
       const char* xs = Xb + (size_t)buf * CC_XBUF;
       const char* ws = Wb + (size_t)buf * CC_WBUF;
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv3x3_chunked_wgrad_kernel(const
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();   // [no LDS reads pending]: none issued since the barrier above
     const char* xs = Xs + (size_t)buf * CW_XBUF;
     const char* ys = Ys + (size_t)buf * CW_YBYTES;
     // this wave's four K steps: pixels [16 s, 16 s + 16) of the tile, s = 4 * quarter .. + 3 (row s >> 1, columns 16 (s & 1) ..);

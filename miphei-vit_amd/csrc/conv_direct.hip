@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const CdArgs p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();                 // ... and so have the other waves' pieces
+    __builtin_amdgcn_s_barrier();                 // ... and so have the other waves' pieces [no LDS reads pending]: none issued since the barrier above
     const char* xs = Xs + (size_t)buf * G::TILE_BYTES;
 
     f32x16 acc[2][NT];
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const CwArgs 
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();   // [no LDS reads pending]: none issued since the barrier above
     const char* xs = Xs + (size_t)buf * G::TILE_BYTES;
     const char* ys = Ys + (size_t)buf * Wg::DY_BYTES;
     // A operand (rows = output channels n, K = pixels): the 16 K steps of the tile, held in registers for all pairs of this wave.

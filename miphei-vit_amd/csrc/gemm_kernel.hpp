@@ -467,6 +467,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       // `tight` steps: the refill is a full dense tile (straight-line DMA code), the whole step is two scheduling
       // regions and the instruction mix is pinned with sched_group_barrier.
       wait_tile(t_begin);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the previous tile's panel reads: finished, not just issued -- once per tile)
       __builtin_amdgcn_s_barrier();
       load_frags(smem + cb * BUF_BYTES, smem + cb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
       constexpr int PG = (LPT + 2) / 3;  // DMA pieces per sub-step

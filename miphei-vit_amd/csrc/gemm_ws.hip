@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();                        // B(-1): K tile 0 has landed
+    __builtin_amdgcn_s_barrier();                        // B(-1): K tile 0 has landed [no LDS reads pending]: producer waves never read LDS
     int g = 0;
     for (int t = 0; t < my_tiles + (has_item ? 1 : 0); ++t) {
       for (int k = 0; k < nk; ++k, ++g) {
@@ -220,9 +220,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();                    // B(g)
+        __builtin_amdgcn_s_barrier();                    // B(g) [no LDS reads pending]: producer
       }
-      __builtin_amdgcn_s_barrier();                      // B'(unit): the consumers are done with the epilogue panel (= stage of step g - 1)
+      __builtin_amdgcn_s_barrier();                      // B'(unit): the consumers are done with the epilogue panel (= stage of step g - 1) [no LDS reads pending]: producer
     }
     return;
   }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   constexpr int NPASS = 16 / RPP;
   const int lc = (lane % CPR) * V, lr = lane / CPR;
 
-  __builtin_amdgcn_s_barrier();                          // B(-1)
+  __builtin_amdgcn_s_barrier();                          // B(-1) [no LDS reads pending]: before the first fragment read
   int stage = 0;
   // One work unit: a 256 x 128 tile (TMc = 4: 64-row wave sub-tiles) or a 64 x 128 item of the ragged band (TMc = 1: 16-row sub-tiles,
   // the A image uses rows 0..63 of the stage); m_base / n0 = its first row / column
@@ -255,10 +255,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       // this wave's rows lie entirely beyond M (ragged last tile row: rows 192.. of a tile with 144 valid rows at M = 5264): it only
       // keeps the block's barriers -- no fragment reads, no MFMAs on zero rows (the loops are power-limited: work that is not done is clock)
       for (int k = 0; k < nk; ++k) {
-        __builtin_amdgcn_s_barrier();                    // B(g)
+        __builtin_amdgcn_s_barrier();                    // B(g) [no LDS reads pending]: a wave without rows reads nothing
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
       }
-      __builtin_amdgcn_s_barrier();                      // B'(unit)
+      __builtin_amdgcn_s_barrier();                      // B'(unit) [no LDS reads pending]
       return;
     }
     f32x4 acc[TMc][TN];
