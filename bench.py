@@ -8,7 +8,7 @@ all-reduce (RCCL) when N>1, global-norm clip + Adam.  Inputs are resident in HBM
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the instantiation with the
 largest share of the step in profiles/r04_kernel_stats_train.txt: the 256x128 MFMA GEMM with the plain store epilogue
 -- qkv forward and the dgrad GEMMs, since round 4 the wave-specialised gemm_ws_kernel<STORE>; algorithmic flops /
-HIP-event durations recorded live on two of the timed steps), `roofline_step` (whole step, algorithmic FLOPs of SURVEY.md 8d / wall time) and `cpu_baseline` (the CPU oracle =
+HIP-event durations recorded live on every fourth launch of ONE of the timed steps), `roofline_step` (whole step, algorithmic FLOPs of SURVEY.md 8d / wall time) and `cpu_baseline` (the CPU oracle =
 port of the reference arithmetic, timed on this host's cores on a bounded sample: 2 warm-ups + median of 5).
 
 `--gpus N` from a plain shell (no WORLD_SIZE in the environment) starts the N ranks itself: the parent never touches
