@@ -64,12 +64,16 @@ static int select_variant(const mvit_gemm_args& a) {
   // problems there, bit 1 every dense 256x128 problem, bit 3 (8) the long-K (>= 4096) ones.  Off by default: since the
   // 8-wave tiles run the same explicitly ordered, register-double-buffered K step they are as fast in the main loop and
   // cheaper in the epilogue (tools/bench_vs_blas.py; whole step 41.3 vs 42.1 ms).
-  MVIT_KNOB(w4, "MVIT_GEMM_W4", 0);
+  // (the 4-wave instantiations -- gemm_dense_w4.hip -- are only compiled into the measurement library, `make dbg`)
   auto id = [](int bm, int bn, int wm, int wn) { return (bm << 20) | (bn << 8) | (wm << 4) | wn; };
-  if (huge) return (w4 & 1) ? id(256, 256, 2, 2) : id(256, 256, 2, 4);
+#ifdef MVIT_DEBUG_KNOBS
+  MVIT_KNOB(w4, "MVIT_GEMM_W4", 0);
+  if (huge && (w4 & 1)) return id(256, 256, 2, 2);
   if (big && dense && (a.N % 128 == 0) && (a.epi != MVIT_EPI_SWIGLU || (w4 & 16)) && a.ksplit <= 1 &&
       ((w4 & 2) || ((w4 & 8) && a.K >= 4096)))
     return id(256, 128, 2, 2);
+#endif
+  if (huge) return id(256, 256, 2, 4);
   if (a.epi == MVIT_EPI_SWIGLU) {
     if ((a.N % 128) || !dense) return -1;
     return big ? id(256, 128, 4, 2) : id(128, 128, 2, 2);
@@ -113,9 +117,11 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   // three-quarters-empty round costs.)
   MVIT_KNOB(ws_band, "MVIT_GEMM_WS_BAND", 1);     // 0: the ragged last tile row always as whole 256-row tiles (measurement)
   if (takes_ws(a, v)) return launch_ws(a, s, ws_band);
+#ifdef MVIT_DEBUG_KNOBS
   if (v == id(256, 256, 2, 2)) return launch_dense<256, 256, 2, 2>(a, s);
-  if (v == id(256, 256, 2, 4)) return launch_dense<256, 256, 2, 4>(a, s);
   if (v == id(256, 128, 2, 2)) return launch_dense<256, 128, 2, 2>(a, s);
+#endif
+  if (v == id(256, 256, 2, 4)) return launch_dense<256, 256, 2, 4>(a, s);
   if (v == id(256, 128, 4, 2)) return dense ? launch_dense<256, 128, 4, 2>(a, s) : launch_conv<256, 128, 4, 2>(a, s);
   if (v == id(128, 128, 2, 2)) return dense ? launch_dense<128, 128, 2, 2>(a, s) : launch_conv<128, 128, 2, 2>(a, s);
   if (v == id(128, 64, 2, 2)) return dense ? launch_dense<128, 64, 2, 2>(a, s) : launch_conv<128, 64, 2, 2>(a, s);

@@ -860,7 +860,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int cb0 = en0 + wave_n * WTN + j * 32;
-            const bool fast = !scalar_io && !atomic && !out_f32 && cb0 + 32 <= p.N;
+            // (C += with bf16 output takes the element path below: ONE rounding of old + new, as every other epilogue of this file
+            //  and of gemm_ws.hip -- the packed path would round the new value before the addition and the sum again)
+            const bool fast = !scalar_io && !atomic && !out_f32 && cb0 + 32 <= p.N && !(p.flags & MVIT_ACCUM_BF16);
             if (fast) {
 #pragma unroll
               for (int pr = 0; pr < 2; ++pr) {      // group pairs (0,1) and (2,3)
@@ -875,16 +877,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
                 uint4 o4 = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                 if (rok) {
                   bf16_t* dst = Cb + (size_t)row * p.ldc + cb0 + 16 * pr + 8 * frag_half;
-                  if (p.flags & MVIT_ACCUM_BF16) {
-                    const uint4 old = *(const uint4*)dst;
-                    const uint32_t uo[4] = {old.x, old.y, old.z, old.w}, un[4] = {o4.x, o4.y, o4.z, o4.w};
-                    uint32_t r_[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                      r_[e] = pack2bf(__uint_as_float(uo[e] << 16) + __uint_as_float(un[e] << 16),
-                                      __uint_as_float(uo[e] & 0xffff0000u) + __uint_as_float(un[e] & 0xffff0000u));
-                    o4 = make_uint4(r_[0], r_[1], r_[2], r_[3]);
-                  }
                   *(uint4*)dst = o4;
                 }
               }

@@ -533,7 +533,7 @@ class HipEngine:
     def _attn_res(self, w, i, train):
         """residual buffer of block i for this forward (None = off).  The A/B switch ``attn_residual`` is latched per forward in
         ``w.ores_on`` so that a toggle between forward and backward cannot make the backward read an unwritten residual."""
-        on = bool(train and self.attn_residual)
+        on = bool(train and self.attn_residual and self._config().lora)   # (only the encoder backward reads it)
         if i == 0:
             w.ores_on = on
         if not w.ores_on:
@@ -583,7 +583,7 @@ class HipEngine:
             ops.gemm(w.o[i], b.wproj, xmid, bias=b.bproj, gamma=b.ls1, aux=xin, epi=EPI_RESID, flags=OUT_F32,
                      rowscale=None if dp is None else dp[l, 0])
             ops.layernorm_fwd(xmid, b.n2w, b.n2b, w.h2, c.eps)
-            ops.gemm(w.h2, b.wfc1, w.g, bias=b.bfc1, aux=(w.u[l] if train else None),
+            ops.gemm(w.h2, b.wfc1, w.g, bias=b.bfc1, aux=(w.u[l] if train and c.lora else None),   # (saved for the encoder backward only)
                      epi=EPI_SWIGLU if c.swiglu else EPI_GELU)
             ops.gemm(w.g, b.wfc2, xout, bias=b.bfc2, gamma=b.ls2, aux=xmid, epi=EPI_RESID, flags=OUT_F32,
                      rowscale=None if dp is None else dp[l, 1])
@@ -749,7 +749,10 @@ class HipEngine:
             raise RuntimeError("backward() needs a preceding forward(train=True)")
         if not sv.bn_train:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the training path")
-        c, fz, fl = self._config(), self._ensure_frozen_bwd(), self._ensure_flat()
+        # (the transposed frozen weights -- 2.2 GB -- are only built when the encoder backward will run: decoder-only training with a
+        #  frozen, adapter-free encoder never reads them)
+        c, fl = self._config(), self._ensure_flat()
+        fz = self._ensure_frozen_bwd() if c.lora else self._ensure_frozen()
         if not c.lora and any(p.requires_grad for p in self.model.encoder.vit.parameters()):
             # get_vitmatte(use_lora=False) leaves every encoder weight trainable (reference mipheivit.py:224-231: full fine-tuning with
             # layer-wise lr decay, models.py:347-357); that needs the weight gradients of 1.1 G frozen-layout parameters and is outside the

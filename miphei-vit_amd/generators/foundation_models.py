@@ -154,7 +154,8 @@ def _load_checkpoint(model, ckpt_path, img_size):
         from safetensors.torch import load_file
         sd = load_file(str(ckpt_path))
     else:
-        sd = torch.load(str(ckpt_path), map_location="cpu")
+        # tensors only: a foundation-model checkpoint is downloaded data, never unpickle arbitrary objects from it
+        sd = torch.load(str(ckpt_path), map_location="cpu", weights_only=True)
     sd = resize_pos_embed_statedict(dict(sd), model, img_size)
     model.load_state_dict(sd)
 

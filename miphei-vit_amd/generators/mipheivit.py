@@ -108,7 +108,7 @@ class Encoder(nn.Module):
             self.scale_factor = (target[0] / self.grid_size[0], target[1] / self.grid_size[1])
             self.interpolate = True
         else:
-            self.scale_factor = (1., 1.)
+            self.scale_factor = None          # as the reference (mipheivit.py:150-157): patch-16 encoders need no re-grid
             self.interpolate = False
 
 

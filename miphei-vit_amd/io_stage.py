@@ -87,3 +87,36 @@ def export_uint8(pred):
     """f32 predictions [B,C,H,W] -> uint8, ((y+0.9)/1.8).clamp(0,1)*255 (truncated)."""
     out = torch.empty(pred.shape, device=pred.device, dtype=torch.uint8)
     return ops.f32_to_u8_export(pred.contiguous(), out)
+
+
+_PERM_CACHE: dict = {}
+
+
+def shuffled_indices(n0: int, count: int, n_tiles: int, seed: int = 0) -> torch.Tensor:
+    """Tile indices of the global samples n0 .. n0 + count - 1 of a shuffled, endlessly repeated pass over `n_tiles` tiles.
+
+    The reference's training DataLoader draws a fresh permutation per epoch (``shuffle=True, drop_last=True``,
+    ``/root/reference/src/dataset.py:117-121``).  Here global sample n belongs to epoch n // n_tiles and takes entry n % n_tiles of
+    that epoch's permutation, drawn from a CPU generator seeded by (seed, epoch): a pure function of (n, seed), so every rank
+    -- whatever the rank layout -- agrees on it without an exchange and a resumed run continues the same stream.  (The stream is
+    continuous: an epoch's tail is not dropped, a batch may straddle two epochs.)"""
+    if n_tiles <= 0 or count < 0:
+        raise ValueError("shuffled_indices: need n_tiles > 0 and count >= 0")
+    out = torch.empty(count, dtype=torch.int64)
+    i = 0
+    while i < count:
+        n = n0 + i
+        epoch, pos = divmod(n, n_tiles)
+        key = (int(seed), int(epoch), int(n_tiles))
+        perm = _PERM_CACHE.get(key)
+        if perm is None:
+            g = torch.Generator(device="cpu")
+            g.manual_seed((int(seed) * 1000003 + int(epoch) * 7919 + 12345) & 0x7FFFFFFFFFFFFFFF)
+            perm = torch.randperm(n_tiles, generator=g)
+            if len(_PERM_CACHE) > 4:
+                _PERM_CACHE.clear()
+            _PERM_CACHE[key] = perm
+        take = min(count - i, n_tiles - pos)
+        out[i:i + take] = perm[pos:pos + take]
+        i += take
+    return out

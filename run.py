@@ -81,10 +81,20 @@ def main(argv):
     if cfg.data.get("val_uint8_tiles"):
         z = np.load(cfg.data.val_uint8_tiles)
         val_tiles = {k: z[k] for k in z.files}
+        # every input check of the validation pass happens HERE, before the first training step: a malformed validation set must
+        # not be discovered after the run (the weights would be lost with it)
+        vi_, vt_ = val_tiles.get("image"), val_tiles.get("target")
+        if vi_ is None or vt_ is None or vi_.dtype != np.uint8 or vi_.ndim != 4 or vi_.shape[3] != 3 or vt_.ndim != 4 \
+                or vt_.shape[3] != nc or vt_.shape[:3] != vi_.shape[:3]:
+            raise ValueError(f"data.val_uint8_tiles: need uint8 image [N,H,W,3] and target [N,H,W,{nc}] of one spatial size")
+        if vi_.shape[1] != S or vi_.shape[2] != S:
+            raise ValueError(f"data.val_uint8_tiles: validation tiles must be {S}x{S} (the reference centre-crops on the CPU)")
         if cfg.train.get("use_cell_metrics"):        # src/train.py:111-114
             from miphei_vit_amd.cells import CellMetrics
             if "nuclei" not in val_tiles or "slide_name" not in val_tiles:
                 raise ValueError("train.use_cell_metrics needs nuclei and slide_name arrays in data.val_uint8_tiles")
+            if val_tiles["nuclei"].shape[:3] != vi_.shape[:3] or len(val_tiles["slide_name"]) != vi_.shape[0]:
+                raise ValueError("data.val_uint8_tiles: nuclei must be [N,H,W] and slide_name [N], matching the images")
             cell_metrics = CellMetrics(sorted(set(str(s_) for s_ in val_tiles["slide_name"])), list(cfg.data.targ_channel_names))
     module = ModelModule(generator, None, cfg.train.learning_rate_g * B ** 0.5, cfg.train.learning_rate_d, loss,
                          cell_metrics=cell_metrics, gan_train=cfg.train.gan_train).to(dev)
@@ -107,7 +117,7 @@ def main(argv):
     every = int(cfg.train.get("checkpoint_every") or 0)
     augment = None
     if tiles is not None:
-        from miphei_vit_amd.io_stage import TrainAugmenter
+        from miphei_vit_amd.io_stage import TrainAugmenter, shuffled_indices
         # counter-based draws: sample n of the run is global (step * world * B + rank * B + b), so a rank layout change does not
         # change what a sample looks like
         augment = TrainAugmenter(dev, (S, S), seed=int(cfg.train.get("seed") or 0))
@@ -115,7 +125,7 @@ def main(argv):
     for i in range(start, steps):
         if augment is not None:
             n0 = (i * world + rank) * B
-            idx = (torch.arange(n0, n0 + B, device=dev) % tiles[0].shape[0])
+            idx = shuffled_indices(n0, B, tiles[0].shape[0], int(cfg.train.get("seed") or 0)).to(dev)
             batch = augment(tiles[0][idx], tiles[1][idx], n0)
         else:
             x, y = synthetic_batch(1234 + rank * 1000 + i, B, S, nc, dev)
@@ -129,12 +139,17 @@ def main(argv):
             save_checkpoint_atomic(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
     module.on_train_end()           # drains the asynchronous NaN guard
     torch.cuda.synchronize()
+    if rank == 0:
+        # the trained weights are on disk before anything else can fail; the throughput line covers the training loop only
+        dt = time.perf_counter() - t0
+        print(f"{steps - start} steps, {world * B * (steps - start) / dt:.1f} tiles/s")
+        save_checkpoint_atomic(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
+        save_pruned_safetensors(generator, os.path.join(logdir, "model.safetensors"))
+        print("saved", os.path.join(logdir, "model.safetensors"))
     if val_tiles is not None and rank == 0:
         from miphei_vit_amd.io_stage import InputStage
         stage = InputStage(dev)
         vi, vt = torch.from_numpy(val_tiles["image"]).to(dev), torch.from_numpy(val_tiles["target"]).to(dev)
-        if vi.shape[1] != S or vi.shape[2] != S:
-            raise ValueError(f"data.val_uint8_tiles: validation tiles must be {S}x{S} (the reference centre-crops on the CPU)")
         losses_v = []
         for j0 in range(0, vi.shape[0], B):
             vb = {"image": stage.image(vi[j0:j0 + B].contiguous()), "target": stage.target(vt[j0:j0 + B].contiguous())}
@@ -147,12 +162,6 @@ def main(argv):
             n_cells = sum(int(t.numel()) for st in module.cell_metrics.state.values() for t in st["cell_id"])
             msg += f", cell_metrics: {n_cells} nuclei over {len(module.cell_metrics.state)} slides"
         print(msg, flush=True)
-    if rank == 0:
-        dt = time.perf_counter() - t0
-        print(f"{steps - start} steps, {world * B * (steps - start) / dt:.1f} tiles/s")
-        save_checkpoint_atomic(module.checkpoint_state(), os.path.join(logdir, "last.ckpt"))
-        save_pruned_safetensors(generator, os.path.join(logdir, "model.safetensors"))
-        print("saved", os.path.join(logdir, "model.safetensors"))
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -49,6 +49,8 @@ def test_state_dict_contract_and_flat_freeze():
     assert hasattr(m, "encoder") and hasattr(m.encoder, "vit") and m.encoder.num_prefix_tokens == 5
     assert m.encoder.grid_size == (9, 9) and m.encoder.embed_dim == 96
     assert abs(m.encoder.scale_factor[0] - 8 / 9) < 1e-12
+    # patch-16 encoders: no re-grid, and the attribute is None as in the reference (mipheivit.py:150-157)
+    assert get_vitmatte("tiny", 128, 3, use_lora=True, pretrained=False).encoder.scale_factor is None
     cfg = {"model": {"model_name": "myvitmatte", "encoder": {"encoder_name": "tiny", "encoder_weights": None,
                                                              "pretrained": False}}}
     g = get_generator("myvitmatte", 128, 3, 3, cfg)
@@ -312,3 +314,21 @@ def test_entry_points_do_not_depend_on_the_benchmark_script():
     for f in ("run.py", "run_inference.py"):
         src = open(os.path.join(ROOT, f)).read()
         assert "from bench" not in src and "import bench" not in src, f
+
+
+def test_shuffled_indices_are_epoch_permutations_shared_by_all_ranks():
+    """run.py's resident-tile sampler (reference: DataLoader(shuffle=True), dataset.py:117-121): every epoch is a permutation of the
+    tile set, different from the previous one, and a pure function of the global sample number -- two rank layouts read the same
+    stream."""
+    from miphei_vit_amd.io_stage import shuffled_indices
+    N, B = 37, 8
+    e0 = shuffled_indices(0, N, N, seed=3)
+    e1 = shuffled_indices(N, N, N, seed=3)
+    assert sorted(e0.tolist()) == list(range(N)) and sorted(e1.tolist()) == list(range(N))
+    assert e0.tolist() != e1.tolist() and e0.tolist() != list(range(N))
+    assert shuffled_indices(0, N, N, seed=4).tolist() != e0.tolist()
+    # world 1 (one rank, batches of 2B) vs world 2 (two ranks, batches of B): the same global samples, straddling an epoch edge
+    one = torch.cat([shuffled_indices(i * 2 * B, 2 * B, N, 3) for i in range(6)])
+    two = torch.cat([torch.cat([shuffled_indices((i * 2 + r) * B, B, N, 3) for r in range(2)]) for i in range(6)])
+    assert torch.equal(one, two)
+    assert torch.equal(one[:N], e0) and torch.equal(one[N:2 * N], e1)
