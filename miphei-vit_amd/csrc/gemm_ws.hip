@@ -44,6 +44,16 @@ constexpr unsigned OOB = 0x80000000u;
 #ifndef MVIT_WS_ABLATE
 #define MVIT_WS_ABLATE 0
 #endif
+// -DMVIT_WS_TIMING (measurement build, tools/ws_timing.py): wave 0 (consumer) and wave 8 (producer) of every block stamp the phases
+// of the block's FIRST work unit with s_memtime (shader cycles) and the block's begin / end with s_memrealtime (100 MHz, common to
+// all CUs) into p.stats (16 x 8 bytes per block): where the fixed cost of a launch goes (launch skew, operand cold start, epilogue)
+#ifdef MVIT_WS_TIMING
+#define WS_STAMP(k, expr) { if (lane == 0 && prof) prof[k] = (long long)(expr); }
+#define WS_CYC() __builtin_readcyclecounter()
+#define WS_RT() __builtin_amdgcn_s_memrealtime()
+#else
+#define WS_STAMP(k, expr)
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr;
 static_assert(PPW == PA + PB, "piece split");
 static_assert((size_t)NCW * SLAB * 4 <= (size_t)BUF_BYTES, "epilogue panels must fit one stage");
@@ -98,6 +108,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   const bool has_item = BAND && (int)blockIdx.x < nq * ord.tiles_n;                // band item of this block: column bx / nq, quarter bx % nq
   const int item_m = rows_full + ((int)blockIdx.x % (nq > 0 ? nq : 1)) * 64, item_n = ((int)blockIdx.x / (nq > 0 ? nq : 1)) * BN;
   const int G = (my_tiles + (has_item ? 1 : 0)) * nk;   // K tiles this block walks (global step index g)
+#ifdef MVIT_WS_TIMING
+  long long* prof = p.stats ? (long long*)p.stats + (size_t)blockIdx.x * 16 + (wave >= NCW ? 8 : 0) : nullptr;
+  if (wave != 0 && wave != NCW) prof = nullptr;
+  WS_STAMP(0, WS_RT())
+  WS_STAMP(1, WS_CYC())
+#endif
 
   if (wave >= NCW) {
     // ================================================================ producers
@@ -203,12 +219,14 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     };
     if (G > 0) issue_next(0);
+    WS_STAMP(2, WS_CYC())
     if (G > 1) {
       issue_next(0);
       wait_older();
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    WS_STAMP(3, WS_CYC())
     __builtin_amdgcn_s_barrier();                        // B(-1): K tile 0 has landed [no LDS reads pending]: producer waves never read LDS
     int g = 0;
     for (int t = 0; t < my_tiles + (has_item ? 1 : 0); ++t) {
@@ -224,6 +242,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       }
       __builtin_amdgcn_s_barrier();                      // B'(unit): the consumers are done with the epilogue panel (= stage of step g - 1) [no LDS reads pending]: producer
     }
+    WS_STAMP(4, WS_CYC())
+    WS_STAMP(5, WS_RT())
     return;
   }
 
@@ -239,6 +259,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   const int lc = (lane % CPR) * V, lr = lane / CPR;
 
   __builtin_amdgcn_s_barrier();                          // B(-1) [no LDS reads pending]: before the first fragment read
+  WS_STAMP(2, WS_CYC())
+#ifdef MVIT_WS_TIMING
+  int units_done = 0;
+#endif
   int stage = 0;
   // One work unit: a 256 x 128 tile (TMc = 4: 64-row wave sub-tiles) or a 64 x 128 item of the ragged band (TMc = 1: 16-row sub-tiles,
   // the A image uses rows 0..63 of the stage); m_base / n0 = its first row / column
@@ -333,6 +357,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     };
     for (int k = 0; k + 1 < nk; ++k) kstep(std::true_type{});
     kstep(std::false_type{});
+#ifdef MVIT_WS_TIMING
+    if (units_done == 0) WS_STAMP(3, WS_CYC())
+#endif
     // `stage` now names the first K tile of the NEXT output tile; the stage consumed last (every consumer is past its reads: the
     // barrier inside the last step) holds the epilogue panels until B'
     const int last = stage == 0 ? NSTAGE - 1 : stage - 1;
@@ -476,6 +503,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         }
       }
     }
+#ifdef MVIT_WS_TIMING
+    if (units_done == 0) WS_STAMP(4, WS_CYC())           // (stores issued, not drained)
+    ++units_done;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (panel reads finished, not just issued: the producers refill this stage behind B')
     __builtin_amdgcn_s_barrier();                        // B'(unit): the panel stage may be refilled
   };
@@ -488,6 +519,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   if constexpr (BAND) {
     if (has_item) run_unit(std::integral_constant<int, 1>{}, item_m, item_n);
   }
+#ifdef MVIT_WS_TIMING
+  WS_STAMP(5, WS_CYC())
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores drained
+  WS_STAMP(6, WS_CYC())
+  WS_STAMP(7, WS_RT())
+#endif
 }
 
 }  // namespace ws
