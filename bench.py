@@ -69,10 +69,58 @@ def parse_args(argv=None):
     ap.add_argument("--attn-residual", type=int, default=1, help="0: attention backward forms D from the bf16 output alone (A/B)")
     ap.add_argument("--lora-group", type=int, default=0, help="ViT blocks per batched LoRA weight-gradient launch (0 = engine default)")
     ap.add_argument("--lora-buckets", type=int, default=4, help="sub-buckets of the LoRA gradient all-reduce (N > 1)")
+    ap.add_argument("--comm-standin", default="16,1000", help="train mode pre-flight, outside the timed region: BLOCKS,USEC of the "
+                    "ring-kernel stand-in launched on a side stream at the five bucket-issue points (csrc/standin.hip); 0 = off")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL; gloo only with --dry")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher / rendezvous / exchange / timing protocol on CPU")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch rendezvous port (0: pick a free one)")
     return ap.parse_args(argv)
+
+
+def comm_overlap_probe(a, mod, eng, sync, step, dev):
+    """What do a collective's kernels cost the compute stream in CU residency?    The wave-specialised
+    GEMM blocks take 504 of a SIMD's 512 registers and 144 KB of LDS: nothing co-resides on a CU, so a ring kernel can only get a CU
+    between GEMM blocks, and while it holds one a one-round GEMM launch (252 tiles on 256 CUs) runs a CU short.  A one-GPU box
+    cannot run RCCL with peers, so the probe launches a stand-in (csrc/standin.hip: BLOCKS workgroups of 256 threads, 64 VGPRs,
+    held for USEC microseconds, no memory traffic) on a side stream at the five points of the backward pass where
+    trainer.DataParallelSync issues its buckets, `finish()` waiting for them as for the all-reduces.  Interleaved A/B outside the
+    timed region: 3 x (6 steps without, 6 with), the same hook points (and grouped LoRA launches) in both arms."""
+    from miphei_vit_amd.trainer import DataParallelSync
+    blocks, usec = (int(v) for v in a.comm_standin.split(","))
+    own = sync is None
+    s2 = DataParallelSync(eng, hooks_only=True, lora_buckets=a.lora_buckets) if own else sync
+    prev = mod.grad_sync
+    mod.grad_sync = s2
+
+    def run(n, base):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            step(base + i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    off, on = [], []
+    base = a.warmup + a.steps + 8
+    try:
+        s2.standin = None
+        run(3, base)
+        for r in range(3):
+            s2.standin = None
+            off.append(run(6, base + 12 * r))
+            s2.standin = (blocks, usec)
+            on.append(run(6, base + 12 * r + 6))
+    finally:
+        s2.standin = None
+        mod.grad_sync = prev
+    m_off, m_on = sum(off) / len(off), sum(on) / len(on)
+    return {"standin_blocks": blocks, "standin_us": usec, "launches_per_step": 1 + a.lora_buckets,
+            "ms_per_step_without": round(m_off, 3), "ms_per_step_with": round(m_on, 3),
+            "delta_pct": round(100.0 * (m_on - m_off) / m_off, 2), "rounds_ms": [[round(x, 3), round(y, 3)] for x, y in zip(off, on)],
+            "note": "stand-in for RCCL ring kernels on a side stream at the bucket-issue points of the backward pass; "
+                    "interleaved A/B outside the timed region; no real peer exchange is part of this number"}
 
 
 def self_launch(a, argv):
@@ -307,6 +355,9 @@ def main(argv=None):
         for i in range(2):
             step(a.warmup + a.steps + i)
         kernels = ops.KPROBE.stop()
+    overlap_probe = None
+    if a.mode == "train" and a.comm_standin not in ("0", "") and hasattr(eng, "grad_buckets"):
+        overlap_probe = comm_overlap_probe(a, mod, eng, sync, step, dev)
     if world > 1:
         dist.barrier()
     if world > 1:
@@ -337,6 +388,9 @@ def main(argv=None):
                        "host_enqueue_ms": [round(t, 2) for t in host_ms],
                        "note": "this rank's timed steps that carried no HIP-event probe (step-boundary events on the compute stream); "
                                "`value` is the contract number over ALL timed steps, probe overhead included"}
+    if a.mode == "train":
+        res["comm_overlap_probe"] = overlap_probe
+        res["multi_gpu_measured"] = bool(world > 1)     # (N = 1 lines: no N > 1 throughput of this build exists in this run)
     if dist.is_initialized():
         res["rccl_ranks"] = dist.get_world_size()
         if comm is not None:

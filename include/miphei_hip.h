@@ -388,6 +388,13 @@ MVIT_API int mvit_cell_means(const float* pred, const float* target, const void*
                              int* n_unique, int* out_ids, float* out_count, float* out_pred, float* out_target,
                              mvit_stream_t stream);
 
+/* ---------------------------------------------------------------- multi-GPU pre-flight helper (measurement, csrc/standin.hip) */
+/* Holds `blocks` workgroups (256 threads, 64 VGPRs per lane, no LDS, no memory traffic) on the chip for `usec` microseconds:
+ * a stand-in for a collective's ring kernels on a one-GPU box.  Replaces nothing in the reference (single-device training,
+ * /root/reference/src/train.py:205-207); used by bench.py --comm-standin to price the CU residency RCCL's kernels take away
+ * from the persistent GEMM launches of the data-parallel step. */
+MVIT_API int mvit_occupy_cus(int blocks, int usec, mvit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -922,12 +922,16 @@ class HipEngine:
                                   rowscale_next=rs(l - 1, 1))
 
     # ------------------------------------------------------------------ fused training step
-    def loss_and_grad(self, out, target, marker_weights, lambda_factor):
+    def loss_and_grad(self, out, target, marker_weights, lambda_factor, grad_scale=1.0):
         """WeightedMSELoss value (device scalar, f64) and dL/d(out) in the workspace."""
         w = self._saved.w
         w.scal.zero_()
         w.sqn_fresh = True
-        ops.wmse_fwd_bwd(out, target.to(torch.float32).contiguous(), marker_weights, w.loss_acc, w.dY, float(lambda_factor))
+        # grad_scale multiplies dL/d(out) only (the loss value keeps lambda_factor): 1/world in data-parallel runs, so that the SUM
+        # all-reduce of the gradient buckets already is the average -- every backward kernel is linear in dY, and for world = 2^k the
+        # scaling commutes with every rounding (bf16 and f32 share the exponent range), i.e. the bits equal a post-exchange division
+        ops.wmse_fwd_bwd(out, target.to(torch.float32).contiguous(), marker_weights, w.loss_acc, w.dY,
+                         float(lambda_factor) * float(grad_scale))
         B, C, H, W = out.shape
         return w.loss_acc * (float(lambda_factor) / (C * B * H * W)), w.dY
 

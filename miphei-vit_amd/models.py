@@ -120,8 +120,10 @@ class ModelModule(_Base):
         if w.device != out.device:
             self.loss_reconstruct.to(out.device)
             w = self.loss_reconstruct.marker_weights
-        loss, dY = eng.loss_and_grad(out, y.to(out.device), w, self.loss_reconstruct.lambda_factor)
         sync = self.grad_sync
+        # data parallel: the 1/world average rides on dL/d(out) (no pass over the gradient buffer after the exchange)
+        gs = sync.begin_step() if sync is not None and hasattr(sync, "begin_step") else 1.0
+        loss, dY = eng.loss_and_grad(out, y.to(out.device), w, self.loss_reconstruct.lambda_factor, grad_scale=gs)
         getattr(eng, "backward_fused", eng.backward)(dY, on_decoder_done=(sync.decoder_ready if sync is not None else None),
                                                      on_lora_block_done=(sync.lora_block_done if sync is not None else None))
         if sync is not None:

@@ -530,6 +530,11 @@ def pix_metrics_scratch_doubles(B):
     return int(L.lib().mvit_pix_metrics_scratch_bytes(B)) // 8
 
 
+def occupy_cus(blocks, usec):
+    """multi-GPU pre-flight stand-in (csrc/standin.hip): hold `blocks` workgroups for `usec` microseconds on the current stream"""
+    _call("mvit_occupy_cus", int(blocks), int(usec))
+
+
 def wmse_fwd_bwd(pred, target, w, loss_acc, dY, lambda_factor):
     B, Cc, H, W = pred.shape
     _call("mvit_wmse_fwd_bwd", _p(pred), _p(target), _p(w), _p(loss_acc), _p(dY), B, Cc, H * W, lambda_factor)

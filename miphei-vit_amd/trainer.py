@@ -23,13 +23,21 @@ class DataParallelSync:
     gradients -- the flat layout is per block, so blocks ``hi..lo`` are one slice -- each issued by ``lora_block_done(l)``
     as soon as block ``lo`` of its range has produced its dA/dB.  Every all-reduce runs on the backend's own stream
     (RCCL's on ROCm), so only the last sub-bucket (``n_lora / lora_buckets`` floats; < 2 MB for H-Optimus-0 with 4) can be
-    exposed.  ``finish`` waits for all of them on the compute stream and applies the 1/world average; with ``timing`` on it
-    brackets that wait with events: the time the compute stream was held back by communication."""
+    exposed.  ``finish`` waits for all of them on the compute stream (the 1/world average already rides on dL/d(out), see
+    ``begin_step``; without it ``finish`` scales the buffer); with ``timing`` on it brackets that wait with events: the time the
+    compute stream was held back by communication."""
 
-    def __init__(self, engine, group=None, force=False, lora_buckets=4, timing=False):
+    def __init__(self, engine, group=None, force=False, lora_buckets=4, timing=False, standin=None, hooks_only=False):
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.active = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path on one rank
+        self.exchange = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path on one rank
+        # Pre-flight on a one-GPU box (bench.py --comm-standin): `standin = (blocks, usec)` launches csrc/standin.hip on a side
+        # stream at every bucket-issue point -- workgroups that hold CUs the way a collective's ring kernels do -- and `finish`
+        # waits for them; `hooks_only` keeps the five issue points (and the grouped LoRA launches they imply) without launching
+        # anything: the A and B arms of the probe differ in the stand-in alone.
+        self.standin = standin
+        self.active = self.exchange or standin is not None or hooks_only
+        self._side = None
         self.lora_buckets = max(1, int(lora_buckets))
         self.timing = timing
         self.exposed_events = []
@@ -37,6 +45,15 @@ class DataParallelSync:
         self._work = []
         self._issued = []
         self._ranges = None
+        self._prescaled = False       # this step's gradients were produced from dY / world (begin_step): finish() must not divide again
+
+    def begin_step(self):
+        """Factor for dL/d(out) of the step about to run: 1/world when the exchange is active, so that the SUM all-reduce of the
+        buckets IS the average and ``finish`` has no pass over the gradient buffer left (round 5; ``ModelModule.training_step``
+        calls this before ``engine.loss_and_grad``).  Callers that drive ``engine.backward`` themselves and never call it keep the
+        divide-in-finish behaviour."""
+        self._prescaled = bool(self.exchange and self.world > 1)
+        return 1.0 / self.world if self._prescaled else 1.0
 
     def _buffers(self, kind):
         """flat parameter / gradient buffers of the engine (MIPHEI-ViT: one; UNETR baseline: decoder side + LoRA)"""
@@ -47,18 +64,26 @@ class DataParallelSync:
         return [fl.flat if kind == "param" else fl.gflat]
 
     def broadcast_parameters(self, src=0):
-        if self.active:
+        if self.exchange:
             for buf in self._buffers("param"):
                 dist.broadcast(buf, src=src, group=self.group)
             self.engine._pack_key = None
 
     def _issue(self, t):
         if t.numel():
-            if self.timing and t.is_cuda:
+            if self.timing and t.is_cuda and self.exchange:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()                       # on the compute stream, at the point of the backward pass that releases the bucket
                 self._issued.append((t.numel() * t.element_size(), ev))
-            self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.standin is not None and t.is_cuda:
+                from . import ops
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=t.device)
+                self._side.wait_stream(torch.cuda.current_stream())     # ordered behind the bucket's producer, like the all-reduce
+                with torch.cuda.stream(self._side):
+                    ops.occupy_cus(int(self.standin[0]), int(self.standin[1]))
+            if self.exchange:
+                self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def decoder_ready(self):
         if self.active:
@@ -101,9 +126,12 @@ class DataParallelSync:
             self.bucket_events.append([(nb, iss, e0, mk) for (nb, iss), mk in zip(self._issued, marks)])
         self._issued = []
         self._work = []
-        if self.world > 1:
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)        # the stand-in kernels, like the all-reduces, end before clip + Adam
+        if self.world > 1 and not self._prescaled:
             for buf in self._buffers("grad"):
                 buf.mul_(1.0 / self.world)
+        self._prescaled = False
         if self.timing:
             e1.record()
             self.exposed_events.append((e0, e1))

@@ -77,9 +77,13 @@ def _worker(rank, port, lora_buckets, lora_group, unetr, ret):
 
         bwd = getattr(eng, "backward_fused", eng.backward)
 
-        def grads(synced):
+        def grads(synced, pre=False):
             out = eng.forward(x, train=True)
-            _, dY = eng.loss_and_grad(out, y, w, 50.0)
+            # pre: the 1/world average rides on dL/d(out) (DataParallelSync.begin_step, the fused training step's form); otherwise
+            # finish() divides the exchanged buffer
+            gs = sync.begin_step() if pre else 1.0
+            assert gs == (0.5 if pre else 1.0)
+            _, dY = eng.loss_and_grad(out, y, w, 50.0, grad_scale=gs)
             if synced:
                 bwd(dY, on_decoder_done=sync.decoder_ready, on_lora_block_done=sync.lora_block_done)
                 sync.finish()
@@ -89,6 +93,8 @@ def _worker(rank, port, lora_buckets, lora_group, unetr, ret):
 
         g_local = grads(False)
         g_sync = grads(True)
+        g_pre = grads(True, pre=True)
+        rel_pre = float((g_pre - g_sync).norm() / g_sync.norm())   # world = 2: scaling by 1/2 commutes with every rounding
         gl = [torch.empty_like(g_local) for _ in range(2)]
         dist.all_gather(gl, g_local)
         mean = 0.5 * (gl[0] + gl[1])
@@ -103,7 +109,7 @@ def _worker(rank, port, lora_buckets, lora_group, unetr, ret):
         mod.training_step({"image": x, "target": y}, 0)
         dist.all_gather(both, cat("param"))
         same = bool(torch.equal(both[0], both[1]))
-        ret[rank] = (rel, rel_lora, apart, same)
+        ret[rank] = (rel, rel_lora, apart, same, rel_pre)
     finally:
         dist.destroy_process_group()
 
@@ -116,7 +122,7 @@ def test_two_rank_exchange_with_the_hip_engine(lora_buckets, lora_group, unetr):
     mp.spawn(_worker, args=(_free_port(), lora_buckets, lora_group, unetr, ret), nprocs=2, join=True)
     assert len(ret) == 2
     for rank in (0, 1):
-        rel, rel_lora, apart, same = ret[rank]
+        rel, rel_lora, apart, same, rel_pre = ret[rank]
         assert apart > 0.05                       # different minibatches: the local gradients are far apart
         # MIPHEI-ViT engine in its deterministic mode (ordered reductions): the gradient of the second, exchanged run IS the mean
         # of the two ranks' first-run gradients up to the f32 rounding of (a + b) / 2.  The UNETR baseline runs the default mode,
@@ -124,6 +130,8 @@ def test_two_rank_exchange_with_the_hip_engine(lora_buckets, lora_group, unetr):
         # or a slice missed would be O(1) either way.
         if unetr:
             assert rel < 5e-3 and rel_lora < 3e-2, (rel, rel_lora)
+            assert rel_pre < 5e-3, rel_pre
         else:
             assert rel < 1e-6 and rel_lora < 1e-6, (rel, rel_lora)
+            assert rel_pre < 1e-6, rel_pre          # pre-divided dY == divide after the exchange (deterministic mode)
         assert same
