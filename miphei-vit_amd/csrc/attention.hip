@@ -60,7 +60,14 @@ __device__ __forceinline__ bf16x8 join(v4s a, v4s b) {
 struct AttnDims {
   int B, N, H, Dh;
   float scale;
+  // block map without integer divisions (round 5): nx = row blocks per (batch, head) pair, and the multiply-high constants of the
+  // divisions by nx and H, built by the host (make_dims).  A division by a run-time value costs a wave ~25 instructions and two
+  // trips through the vector unit (v_rcp_iflag + readfirstlane); twelve waves per CU ran two of them at once on the CU's one scalar
+  // unit in front of everything else (profiles/r04_attn_timing.txt: 17 % of a wave's cycles before its first tile step).
+  unsigned nx, nx_magic, h_magic;
 };
+// floor(x / d) for x < 2^32 / d: mulhi(x, floor(2^32 / d) + 1); d == 1 has no 32-bit constant
+__device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
 
 // DMA one 64-row x 64-col bf16 tile (rows row0.. of a matrix with row stride `rs` elements) straight into LDS
 // (buffer_load ... lds, 16 B per lane): lane l of a wave fills row l>>3, 16-byte slot l&7 of 8 consecutive rows; the
@@ -147,11 +154,12 @@ __device__ __forceinline__ void store_row_groups(bf16_t* row, int Dh, int half, 
 // pair-major order: the re-reads then hit that XCD's L2 instead of crossing the fabric once per row block
 // (forward: 130 MB -> one pass over q, k, v, o per launch).  Bijective for any block count.
 struct BlockXY { int x, y; };
-__device__ __forceinline__ BlockXY block_xy(int nx) {
+__device__ __forceinline__ BlockXY block_xy(const AttnDims& dm) {
   const int total = gridDim.x, L = blockIdx.x;
   const int q = total >> 3, r = total & 7, xcd = L & 7;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-  return {wg % nx, wg / nx};
+  const int y = (int)fast_div((unsigned)wg, dm.nx, dm.nx_magic);
+  return {wg - y * (int)dm.nx, y};
 }
 
 // ------------------------------------------------------------------ forward
@@ -171,8 +179,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const BlockXY bxy = block_xy((dm.N + 127) / 128);
-  const int bh = bxy.y, b = bh / dm.H, h = bh % dm.H;
+  const BlockXY bxy = block_xy(dm);
+  const int bh = bxy.y, b = (int)fast_div((unsigned)bh, (unsigned)dm.H, dm.h_magic), h = bh - b * dm.H;
   const int N = dm.N, Dh = dm.Dh;
   const size_t rs = (size_t)3 * dm.H * Dh;  // row stride of packed qkv
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
@@ -375,8 +383,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const BlockXY bxy = block_xy((dm.N + 127) / 128);
-  const int bh = bxy.y, b = bh / dm.H, h = bh % dm.H;
+  const BlockXY bxy = block_xy(dm);
+  const int bh = bxy.y, b = (int)fast_div((unsigned)bh, (unsigned)dm.H, dm.h_magic), h = bh - b * dm.H;
   const int N = dm.N, Dh = dm.Dh;
   const size_t rs = (size_t)3 * dm.H * Dh, ors = (size_t)dm.H * Dh;
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
@@ -527,8 +535,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][Q|dO] + L[Npad] + D[Npad] (f32)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const BlockXY bxy = block_xy((dm.N + 127) / 128);
-  const int bh = bxy.y, b = bh / dm.H, h = bh % dm.H;
+  const BlockXY bxy = block_xy(dm);
+  const int bh = bxy.y, b = (int)fast_div((unsigned)bh, (unsigned)dm.H, dm.h_magic), h = bh - b * dm.H;
   const int N = dm.N, Dh = dm.Dh;
   const size_t rs = (size_t)3 * dm.H * Dh, ors = (size_t)dm.H * Dh;
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * Dh;
@@ -673,13 +681,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 }  // namespace
 
+static bool make_dims(AttnDims& dm, int B, int N, int H, int Dh, float scale) {
+  const unsigned nx = (unsigned)((N + 127) / 128);
+  const unsigned long long total = (unsigned long long)nx * (unsigned)B * (unsigned)H;
+  const unsigned dmax = nx > (unsigned)H ? nx : (unsigned)H;
+  if (total * dmax >= 0xffffffffull) return false;           // (fast_div's range; also keeps the 1-D grid far below its limit)
+  dm = AttnDims{B, N, H, Dh, scale, nx, (unsigned)(0x100000000ull / nx) + 1u, (unsigned)(0x100000000ull / (unsigned)H) + 1u};
+  return true;
+}
+
 extern "C" {
 
 MVIT_API int mvit_attention_fwd(const void* qkv, void* out, void* out_res, float* lse, int B, int N, int H, int Dh, float scale,
                                 mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
-  AttnDims dm{B, N, H, Dh, scale};
+  AttnDims dm;
+  if (!make_dims(dm, B, N, H, Dh, scale)) return MVIT_EINVAL;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, (hipStream_t)stream,
                      (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)out_res, lse, dm);
   return MVIT_LAUNCH_CHECK();
@@ -689,7 +707,8 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* ou
                                 float* dsum, void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream) {
   MVIT_CLEAR_ERROR();
   if (B <= 0 || N <= 0 || H <= 0 || Dh <= 0 || Dh > 64 || (Dh & 7)) return MVIT_EINVAL;
-  AttnDims dm{B, N, H, Dh, scale};
+  AttnDims dm;
+  if (!make_dims(dm, B, N, H, Dh, scale)) return MVIT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
                      (const bf16_t*)out, (const bf16_t*)out_res, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);

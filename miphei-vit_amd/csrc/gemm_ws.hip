@@ -39,6 +39,14 @@ constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4;
 constexpr int SLD = WTN + 4, SLAB = 16 * SLD;        // wave-private epilogue panel: 16 rows x 68 floats
 constexpr int V = 8;
 constexpr unsigned OOB = 0x80000000u;
+// Single-round residual epilogue (round 5, flag 0x4000, see launch_ws): the accumulator tile is parked whole in LDS (the operand
+// stages are dead by then), [BM][PARK_LD] floats; the producer waves, which fetched the tile's residual rows into their otherwise
+// idle registers during the K loop, finish it
+constexpr int PARK_LD = BN + 4;                      // row stride in floats: 16-byte aligned rows, conflict-free b128 reads
+constexpr int RES_PASSES = BM / NPW / 2;             // a producer wave owns BM / NPW = 64 rows, two rows (2 x 128 floats) per pass = 32
+constexpr int RES_PER_STEP = 4, RES_STEPS = RES_PASSES / RES_PER_STEP;   // residual loads ride on the first 8 K steps, 4 per step
+static_assert((size_t)BM * PARK_LD * 4 <= (size_t)NSTAGE * BUF_BYTES, "parked tile must fit the operand stages");
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // measurement builds (make DEBUG_KNOBS=1 BUILD=build_aN LIB=../libmiphei_aN.so EXTRA=-DMVIT_WS_ABLATE=N; results are garbage):
 // bit 0 no operand DMA, bit 1 no MFMAs, bit 2 no fragment reads (tools/bench_ws_abl.py)
 #ifndef MVIT_WS_ABLATE
@@ -194,6 +202,93 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * 1024), 16, voB2[j], 0, 0, 0);
       }
     };
+    if constexpr (EPI == MVIT_EPI_RESID && !BAND) {
+      if (p.flags & 0x4000) {
+        // ---- single round (every block owns exactly one tile), residual epilogue on the producer side.
+        // The residual tile (BM x BN f32 = 128 KB per block) is what the plain epilogue waits for with the matrix pipe idle: 252
+        // blocks reach their epilogue together and ask for 32 MB at once (tools/ws_timing.py: 11-25 k cycles against 3 k for the
+        // plain store).  Here each producer wave requests its 64 rows (32 x 16-byte loads per lane = 128 registers it otherwise
+        // never uses) during the first RES_STEPS K steps, behind the step's operand DMA; the consumers park the accumulators in
+        // LDS after the last K step; the producers add and store.  Loads return in order: the counted waits below allow exactly
+        // the requests younger than the K tile that is about to be published.
+        set_unit(0);
+        int m0, n0;
+        ord.get(blockIdx.x, m0, n0);
+        const unsigned vm = (unsigned)min(BM, p.M - m0);
+        const float* rsrc_p = p.aux ? (const float*)p.aux : (const float*)p.C;
+        const int ldr = p.aux ? p.ldaux : p.ldc;
+        // descriptors ranged to the tile's valid rows: rows beyond M load zeros / drop their stores (no row tests below)
+        const __amdgpu_buffer_rsrc_t rsR = make_rsrc(rsrc_p + (size_t)m0 * ldr + n0, vm * (unsigned)ldr * 4u - (unsigned)0);
+        const __amdgpu_buffer_rsrc_t rsC = make_rsrc((float*)p.C + (size_t)m0 * p.ldc + n0, vm * (unsigned)p.ldc * 4u);
+        const int c4 = (lane & 31) * 4, rhalf = lane >> 5;
+        const unsigned voR = (unsigned)rhalf * (unsigned)ldr * 4u + (unsigned)c4 * 4u;
+        const unsigned voC = (unsigned)rhalf * (unsigned)p.ldc * 4u + (unsigned)c4 * 4u;
+        f32x4 gam4 = {1.f, 1.f, 1.f, 1.f}, bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.gamma) gam4 = *(const f32x4*)(p.gamma + n0 + c4);
+        if (p.bias) bias4 = *(const f32x4*)(p.bias + n0 + c4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (column constants: before the counted requests start)
+        u32x4 res[RES_PASSES];
+        // (the row advance rides on the VECTOR offset: the scalar offset is outside the descriptor's range check)
+        unsigned ro = voR + (unsigned)(pw * (BM / NPW)) * (unsigned)ldr * 4u;
+        const unsigned rstep = 2u * (unsigned)ldr * 4u;
+        auto issue_res = [&](int i0) __attribute__((always_inline)) {
+#pragma unroll
+          for (int j = 0; j < RES_PER_STEP; ++j) {
+            res[i0 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsR, ro, 0, 0);
+            ro += rstep;
+          }
+        };
+        int st = 0;
+        auto next_stage = [&]() __attribute__((always_inline)) { const int c = st; st = st + 1 == NSTAGE ? 0 : st + 1; return c; };
+        issue(0, next_stage(), false, 0);
+        issue(1, next_stage(), false, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        WS_STAMP(2, WS_CYC())
+        WS_STAMP(3, WS_CYC())
+        __builtin_amdgcn_s_barrier();                    // B(-1) [no LDS reads pending]: producer
+        // steps 0 .. RES_STEPS - 1 carry the residual requests (unrolled: `res` is a register array)
+#pragma unroll
+        for (int g = 0; g < RES_STEPS; ++g) {
+          issue(g + 2, next_stage(), false, 0);
+          issue_res(g * RES_PER_STEP);
+          // in flight, oldest first: K tile g + 1 | residuals of step g - 1 | K tile g + 2 | residuals of step g
+          if (g == 0)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + RES_PER_STEP) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * RES_PER_STEP) : "memory");
+          __builtin_amdgcn_s_barrier();                  // B(g) [no LDS reads pending]: producer
+        }
+        issue(RES_STEPS + 2, next_stage(), false, 0);    // (nk >= RES_STEPS + 3: launch_ws)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + RES_PER_STEP) : "memory");
+        __builtin_amdgcn_s_barrier();                    // B(RES_STEPS) [no LDS reads pending]: producer
+        for (int g = RES_STEPS + 1; g < nk; ++g) {
+          if (g + 2 < nk) {
+            issue(g + 2, next_stage(), false, 0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_s_barrier();                  // B(g) [no LDS reads pending]: producer
+        }
+        __builtin_amdgcn_s_barrier();                    // B'(unit): the accumulator tile is parked [no LDS reads pending]: the producer's reads start below
+        const float* park = (const float*)smem + (size_t)(pw * (BM / NPW) + rhalf) * PARK_LD + c4;
+        unsigned co = voC + (unsigned)(pw * (BM / NPW)) * (unsigned)p.ldc * 4u;
+        const unsigned cstep = 2u * (unsigned)p.ldc * 4u;
+#pragma unroll
+        for (int i = 0; i < RES_PASSES; ++i) {
+          const f32x4 a = *(const f32x4*)(park + (size_t)(2 * i) * PARK_LD);
+          const f32x4 r = __builtin_bit_cast(f32x4, res[i]);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = r[e] + gam4[e] * (a[e] + bias4[e]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, co, 0, 0);
+          co += cstep;
+        }
+        WS_STAMP(4, WS_CYC())
+        WS_STAMP(5, WS_RT())
+        return;
+      }
+    }
     // look-ahead cursor: the next K tile to request
     int l_unit = 0, l_k = 0, l_stage = 0, l_g = 0;
     bool l_item = my_tiles == 0;                          // the unit under the cursor is the band item (12 vs 6 pieces per request)
@@ -360,6 +455,26 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 #ifdef MVIT_WS_TIMING
     if (units_done == 0) WS_STAMP(3, WS_CYC())
 #endif
+    if constexpr (EPI == MVIT_EPI_RESID && !BAND && TMc == 4) {
+      if (p.flags & 0x4000) {
+        // single round: park the whole accumulator sub-tile (every wave is past its last fragment read -- the barrier inside the
+        // last K step -- and no DMA is in flight: all three stages are free), the producer waves finish the tile (see above)
+        float* park = (float*)smem + (size_t)(wave_m * WTM + 4 * fh) * PARK_LD + wave_n * WTN + fr;
+#pragma unroll
+        for (int i = 0; i < TMc; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) park[(i * 16 + r4) * PARK_LD + j * 16] = acc[i][j][r4];
+#ifdef MVIT_WS_TIMING
+        if (units_done == 0) WS_STAMP(4, WS_CYC())
+        ++units_done;
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the parked values are in LDS before the hand-over
+        __builtin_amdgcn_s_barrier();                        // B'(unit)
+        return;
+      }
+    }
     // `stage` now names the first K tile of the NEXT output tile; the stage consumed last (every consumer is past its reads: the
     // barrier inside the last step) holds the epilogue panels until B'
     const int last = stage == 0 ? NSTAGE - 1 : stage - 1;
@@ -531,7 +646,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 
 // problems the wave-specialised kernel takes (everything else stays on gemm_kernel.hpp)
 bool ws_supported(const mvit_gemm_args& a) {
-  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000))) return false;
+  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000 | 0x4000))) return false;
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_SWIGLU && a.epi != MVIT_EPI_RESID && a.epi != MVIT_EPI_DSWIGLU) return false;
   if (a.M < 1024 || (a.N % 128) || (a.K % 64) || a.K < 64) return false;
   if (a.A2 && (a.K2 > 64 || a.K2 <= 0)) return false;
@@ -569,13 +684,17 @@ bool ws_band_mode(const mvit_gemm_args& a) {
   return rounds_full < rounds_all && (rf * nt) % cus == 0 && items <= cus;
 }
 
-int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob) {
+int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_single_knob) {
   mvit_gemm_args a = a0;
-  a.flags &= ~0x2000;
+  a.flags &= ~(0x2000 | 0x4000);
   if (band_knob && ws_band_mode(a)) {
     a.flags |= 0x2000;
     return a.epi == MVIT_EPI_STORE ? launch_ws_one<MVIT_EPI_STORE, true>(a, s) : launch_ws_one<MVIT_EPI_SWIGLU, true>(a, s);
   }
+  // single-round residual epilogue on the producer waves (every block owns one tile, enough K steps to carry the residual requests)
+  if (a.epi == MVIT_EPI_RESID && resid_single_knob && (long long)((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN) <= gemm_num_cus() &&
+      a.K / ws::BK >= ws::RES_STEPS + 3 && !a.A2)
+    a.flags |= 0x4000;
   switch (a.epi) {
     case MVIT_EPI_STORE: return launch_ws_one<MVIT_EPI_STORE, false>(a, s);
     case MVIT_EPI_SWIGLU: return launch_ws_one<MVIT_EPI_SWIGLU, false>(a, s);

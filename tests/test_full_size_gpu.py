@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 # the test) + 25 %
 # (B = 2, round-5 build: decoder 0.158 -- convstream.convs.0.conv.weight, autocast 0.196 --, LoRA block 0 / 20 / 39: 0.056 / 0.053 / 0.054)
 ABS_CEIL = {2: {"decoder": 0.20, "lora0": 0.070, "lora20": 0.067, "lora39": 0.067},
-            16: {"decoder": 0.20, "lora0": 0.070, "lora20": 0.067, "lora39": 0.067}}
+            # (B = 16: decoder 0.110, LoRA block 0 / 20 / 39: 0.025 / 0.064 / 0.038; autocast on the same tensors 0.244 / 0.026 / 0.069 / 0.048)
+            16: {"decoder": 0.14, "lora0": 0.031, "lora20": 0.080, "lora39": 0.047}}
 
 
 # (16, 256) = BASELINE.json configs[1] itself: 256-row GEMM tiles, M = 5264 (about 40 s of CPU oracle);

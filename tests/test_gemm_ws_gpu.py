@@ -130,3 +130,35 @@ def test_ws_band_mode_ragged_rows(M, N, K):
         a_ref, b_ref = pre[:, :, 0].reshape(M, H), pre[:, :, 1].reshape(M, H)
         assert _rel(u.float(), ref) < 4e-3
         assert _rel(gate[:M].float(), torch.nn.functional.silu(a_ref) * b_ref) < 6e-3 and float((gate[M:].float() - 5.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(5264, 1536, 1536), (5121, 1536, 704), (5375, 1536, 704), (4100, 2048, 768), (5264, 1536, 640), (300 + 1024, 128, 1536)])
+def test_ws_single_round_residual_on_the_producer_waves(M, N, K):
+    """One-round LayerScale + residual launches (every block owns one tile, >= 11 K tiles: proj and fc2 of the batch-16 step): the
+    residual rows are fetched by the producer waves during the K loop, the accumulators parked in LDS and finished there
+    (csrc/gemm_ws.hip, flag 0x4000).  Ragged last tile rows (1 and 255 valid rows), guard rows behind the output, leading dimensions
+    larger than the extents, no bias / no LayerScale, the in-place form, K just below the threshold (640: the consumer-side epilogue)."""
+    import miphei_vit_amd.ops as ops
+    assert _is_ws(M, N, K, epi=ops.EPI_RESID, flags=ops.OUT_F32)
+    g = torch.Generator(device="cuda").manual_seed(M + 7 * K)
+    a, b = _rnd(g, M, K), _rnd(g, N, K, scale=K ** -0.5)
+    bias, gam = _rnd(g, N, dt=torch.float32), _rnd(g, N, dt=torch.float32)
+    ldr, ldo = N + 64, N + 32
+    resb = _rnd(g, M, ldr, dt=torch.float32)
+    res = resb[:, :N]
+    lin = a.float() @ b.float().t()
+    outb = torch.full((M + 5, ldo), 3.0, device="cuda", dtype=torch.float32)
+    ops.gemm(a, b, outb, M=M, bias=bias, gamma=gam, aux=resb, ldaux=ldr, ldc=ldo, epi=ops.EPI_RESID, flags=ops.OUT_F32)
+    tol = 1e-5 * K ** 0.5 + 2e-6
+    assert _rel(outb[:M, :N] - res, gam * (lin + bias)) < tol
+    assert float((outb[M:] - 3.0).abs().max()) == 0.0 and float((outb[:, N:] - 3.0).abs().max()) == 0.0   # nothing beyond M rows / N columns
+    out2 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm(a, b, out2, aux=res.contiguous(), epi=ops.EPI_RESID, flags=ops.OUT_F32)                       # no bias, no LayerScale
+    assert _rel(out2 - res, lin) < tol
+    out3 = res.contiguous().clone()                                                                        # in place
+    ops.gemm(a, b, out3, bias=bias, gamma=gam, epi=ops.EPI_RESID, flags=ops.OUT_F32)
+    assert torch.equal(out3, outb[:M, :N].contiguous())
+    for _ in range(20):                                                                                    # run-to-run identical
+        out4 = res.contiguous().clone()
+        ops.gemm(a, b, out4, bias=bias, gamma=gam, epi=ops.EPI_RESID, flags=ops.OUT_F32)
+        assert torch.equal(out4, out3)
