@@ -44,7 +44,10 @@ constexpr unsigned OOB = 0x80000000u;
 // idle registers during the K loop, finish it
 constexpr int PARK_LD = BN + 4;                      // row stride in floats: 16-byte aligned rows, conflict-free b128 reads
 constexpr int RES_PASSES = BM / NPW / 2;             // a producer wave owns BM / NPW = 64 rows, two rows (2 x 128 floats) per pass = 32
-constexpr int RES_PER_STEP = 4, RES_STEPS = RES_PASSES / RES_PER_STEP;   // residual loads ride on the first 8 K steps, 4 per step
+#ifndef MVIT_WS_RES_PER_STEP
+#define MVIT_WS_RES_PER_STEP 4
+#endif
+constexpr int RES_PER_STEP = MVIT_WS_RES_PER_STEP, RES_STEPS = RES_PASSES / RES_PER_STEP;   // residual loads ride on the first 32 / RES_PER_STEP K steps
 static_assert((size_t)BM * PARK_LD * 4 <= (size_t)NSTAGE * BUF_BYTES, "parked tile must fit the operand stages");
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // measurement builds (make DEBUG_KNOBS=1 BUILD=build_aN LIB=../libmiphei_aN.so EXTRA=-DMVIT_WS_ABLATE=N; results are garbage):
@@ -223,10 +226,6 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         const int c4 = (lane & 31) * 4, rhalf = lane >> 5;
         const unsigned voR = (unsigned)rhalf * (unsigned)ldr * 4u + (unsigned)c4 * 4u;
         const unsigned voC = (unsigned)rhalf * (unsigned)p.ldc * 4u + (unsigned)c4 * 4u;
-        f32x4 gam4 = {1.f, 1.f, 1.f, 1.f}, bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.gamma) gam4 = *(const f32x4*)(p.gamma + n0 + c4);
-        if (p.bias) bias4 = *(const f32x4*)(p.bias + n0 + c4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (column constants: before the counted requests start)
         u32x4 res[RES_PASSES];
         // (the row advance rides on the VECTOR offset: the scalar offset is outside the descriptor's range check)
         unsigned ro = voR + (unsigned)(pw * (BM / NPW)) * (unsigned)ldr * 4u;
@@ -242,7 +241,11 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         auto next_stage = [&]() __attribute__((always_inline)) { const int c = st; st = st + 1 == NSTAGE ? 0 : st + 1; return c; };
         issue(0, next_stage(), false, 0);
         issue(1, next_stage(), false, 0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        // column constants: two unconditional loads BEHIND the first operand requests (a null pointer reads the output's first
+        // columns instead and the value is replaced below), counted in the waits like the residual requests
+        const u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.gamma ? (const void*)(p.gamma + n0) : (const void*)p.C, BN * 4u), (unsigned)c4 * 4u, 0, 0);
+        const u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.bias ? (const void*)(p.bias + n0) : (const void*)p.C, BN * 4u), (unsigned)c4 * 4u, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2) : "memory");
         WS_STAMP(2, WS_CYC())
         WS_STAMP(3, WS_CYC())
         __builtin_amdgcn_s_barrier();                    // B(-1) [no LDS reads pending]: producer
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           issue(g + 2, next_stage(), false, 0);
           issue_res(g * RES_PER_STEP);
           // in flight, oldest first: K tile g + 1 | residuals of step g - 1 | K tile g + 2 | residuals of step g
-          if (g == 0)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + RES_PER_STEP) : "memory");
+          if (g == 0)      // (K tile 1 | the two column-constant loads | K tile 2 | residuals of step 0)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + RES_PER_STEP + 2) : "memory");
           else
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * RES_PER_STEP) : "memory");
           __builtin_amdgcn_s_barrier();                  // B(g) [no LDS reads pending]: producer
@@ -271,6 +274,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           __builtin_amdgcn_s_barrier();                  // B(g) [no LDS reads pending]: producer
         }
         __builtin_amdgcn_s_barrier();                    // B'(unit): the accumulator tile is parked [no LDS reads pending]: the producer's reads start below
+        const f32x4 gam4 = p.gamma ? __builtin_bit_cast(f32x4, gq) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        const f32x4 bias4 = p.bias ? __builtin_bit_cast(f32x4, bq) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* park = (const float*)smem + (size_t)(pw * (BM / NPW) + rhalf) * PARK_LD + c4;
         unsigned co = voC + (unsigned)(pw * (BM / NPW)) * (unsigned)p.ldc * 4u;
         const unsigned cstep = 2u * (unsigned)p.ldc * 4u;

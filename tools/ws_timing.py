@@ -18,7 +18,9 @@ import miphei_vit_amd.ops as ops
 M = 16 * 329
 shapes = [("dproj", M, 1536, 1536, "store"), ("dqkv", M, 1536, 4608, "store"), ("dfc1", M, 1536, 8192, "store"),
           ("qkv", M, 4608, 1536, "store"), ("dfc2", M, 4096, 1536, "store"), ("proj+res", M, 1536, 1536, "resid"),
-          ("fc2+res", M, 1536, 4096, "resid")]
+          ("fc2+res", M, 1536, 4096, "resid"), ("fc1+swiglu", M, 8192, 1536, "swiglu"), ("dfc2+dswiglu", M, 4096, 1536, "dswiglu")]
+if os.environ.get("WS_TIMING_ONLY"):
+    shapes = [s_ for s_ in shapes if s_[0] in os.environ["WS_TIMING_ONLY"].split(",")]
 NB = 256
 
 
@@ -32,6 +34,12 @@ def run(name, m, n, k, epi, warm_prev=None):
     if epi == "store":
         c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
         kw = {}
+    elif epi == "swiglu":      # n = 2 * hidden packed [a32 | b32]; output [m, n / 2], saved pre-activation [m, n]
+        c = torch.empty(m, n // 2, device="cuda", dtype=torch.bfloat16)
+        kw = dict(aux=torch.empty(m, n, device="cuda", dtype=torch.bfloat16), bias=torch.zeros(n, device="cuda"), epi=ops.EPI_SWIGLU)
+    elif epi == "dswiglu":     # n = hidden; output [m, 2 n] packed, saved pre-activation [m, 2 n]
+        c = torch.empty(m, 2 * n, device="cuda", dtype=torch.bfloat16)
+        kw = dict(aux=torch.randn(m, 2 * n, device="cuda").bfloat16(), epi=ops.EPI_DSWIGLU)
     else:
         c = torch.empty(m, n, device="cuda", dtype=torch.float32)
         kw = dict(aux=torch.randn(m, n, device="cuda"), gamma=torch.ones(n, device="cuda"), bias=torch.zeros(n, device="cuda"),
