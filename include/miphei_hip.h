@@ -395,14 +395,6 @@ MVIT_API int mvit_cell_means(const float* pred, const float* target, const void*
  * from the persistent GEMM launches of the data-parallel step. */
 MVIT_API int mvit_occupy_cus(int blocks, int usec, mvit_stream_t stream);
 
-/* Infinity-Cache warmer: touches one dword per 128-byte line of [p, p + bytes) with non-temporal loads from `waves` one-wave
- * workgroups (2 vector registers per lane, no LDS: they run beside the persistent GEMM blocks) and discards the values, so that a
- * tensor the backward pass is about to re-read (saved activations of timm's Block: SwiGLU pre-activation, LayerNorm inputs, packed
- * qkv -- /root/reference/src/generators/foundation_models.py:53-57 through autograd) comes from the 256 MB memory-side cache instead
- * of HBM.  `pace` x 64 idle cycles between two 8 KB touches of a wave (0 = as fast as the memory system takes them).  Launched on a
- * side stream ahead of the consumer (engine.py); never changes a result. */
-MVIT_API int mvit_prefetch_cache(const void* p, long long bytes, int waves, int pace, mvit_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -535,12 +535,6 @@ def occupy_cus(blocks, usec):
     _call("mvit_occupy_cus", int(blocks), int(usec))
 
 
-def prefetch_cache(t, waves=256, pace=0):
-    """Infinity-Cache warmer (csrc/standin.hip): touch every 128-byte line of the tensor's storage extent on the current stream"""
-    assert t.is_contiguous()
-    _call("mvit_prefetch_cache", _p(t), t.numel() * t.element_size(), int(waves), int(pace))
-
-
 def wmse_fwd_bwd(pred, target, w, loss_acc, dY, lambda_factor):
     B, Cc, H, W = pred.shape
     _call("mvit_wmse_fwd_bwd", _p(pred), _p(target), _p(w), _p(loss_acc), _p(dY), B, Cc, H * W, lambda_factor)
