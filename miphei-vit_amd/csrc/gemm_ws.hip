@@ -50,6 +50,18 @@ constexpr int RES_PASSES = BM / NPW / 2;             // a producer wave owns BM 
 constexpr int RES_PER_STEP = MVIT_WS_RES_PER_STEP, RES_STEPS = RES_PASSES / RES_PER_STEP;   // residual loads ride on the first 32 / RES_PER_STEP K steps
 static_assert((size_t)BM * PARK_LD * 4 <= (size_t)NSTAGE * BUF_BYTES, "parked tile must fit the operand stages");
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// d(SwiGLU) epilogue operand as PSEUDO K TILES (round 5).  The saved pre-activation of a tile (256 rows x 256 packed bf16 = 128 KB)
+// used to be requested by the consumer waves at the start of the epilogue, the matrix pipe idle until it arrived (tools/ws_timing.py:
+// 13.5 k cycles per tile against 3.1 k for the plain store; more when the tensor comes from HBM, as it does in the backward pass).
+// Now the producer waves DMA it into the operand ring behind the tile's last K tile, as NPSEUDO more "K tiles" -- one per 16-row
+// accumulator slab, the slab's rows of all eight consumer waves (8 x 16 rows x 256 B = 32 KB of the 48 KB stage) -- two steps ahead
+// like every other request, published through the same per-step barrier; the consumers' epilogue becomes NPSEUDO ring steps that
+// read the operand from LDS and never wait on the vector-memory counter.  The wave-private accumulator panels (16 x 64 floats,
+// XOR-swizzled instead of padded: exactly 4 KB) live in the 16 KB of the stage the pseudo tile leaves free (waves 0-3) and in
+// 16 KB behind the ring (waves 4-7): 160 KB of LDS in all.
+constexpr int NPSEUDO = 4, PS_WAVE_BYTES = 16 * 256, PS_BYTES = NCW * PS_WAVE_BYTES, PS_PPW = PS_BYTES / 1024 / NPW;   // 8 pieces per producer wave
+constexpr int PANEL_BYTES = 16 * 64 * 4;
+static_assert(PS_BYTES + 4 * PANEL_BYTES <= BUF_BYTES, "pseudo tile + four panels must fit a stage");
 // measurement builds (make DEBUG_KNOBS=1 BUILD=build_aN LIB=../libmiphei_aN.so EXTRA=-DMVIT_WS_ABLATE=N; results are garbage):
 // bit 0 no operand DMA, bit 1 no MFMAs, bit 2 no fragment reads (tools/bench_ws_abl.py)
 #ifndef MVIT_WS_ABLATE
@@ -115,10 +127,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   const int nk1 = p.K / BK;
   const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
   const int nk = nk1 + nk2;
+  constexpr int NPS = (EPI == MVIT_EPI_DSWIGLU && !BAND) ? NPSEUDO : 0;   // pseudo K tiles behind every unit's real ones
+  const int nks = nk + NPS;                                                // ring steps per unit
   const int my_tiles = ((int)blockIdx.x < ord.ntiles) ? (ord.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const bool has_item = BAND && (int)blockIdx.x < nq * ord.tiles_n;                // band item of this block: column bx / nq, quarter bx % nq
   const int item_m = rows_full + ((int)blockIdx.x % (nq > 0 ? nq : 1)) * 64, item_n = ((int)blockIdx.x / (nq > 0 ? nq : 1)) * BN;
-  const int G = (my_tiles + (has_item ? 1 : 0)) * nk;   // K tiles this block walks (global step index g)
+  const int G = (my_tiles + (has_item ? 1 : 0)) * nks;  // ring steps this block walks (global step index g)
 #ifdef MVIT_WS_TIMING
   long long* prof = p.stats ? (long long*)p.stats + (size_t)blockIdx.x * 16 + (wave >= NCW ? 8 : 0) : nullptr;
   if (wave != 0 && wave != NCW) prof = nullptr;
@@ -155,7 +169,18 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       voB[j] = (unsigned)row * (unsigned)p.ldb * 2u + (unsigned)cs * 16u;
       voB2[j] = (cs * 8 < p.K2) ? (unsigned)row * (unsigned)p.ldb2 * 2u + (unsigned)cs * 16u : OOB;
     }
-    __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2;
+    // pseudo tiles: piece j of this wave = rows 4 q .. 4 q + 3 (q = j % 4) of consumer wave cw = 2 pw + j / 4's slab; lane l holds
+    // row l / 16, 16-byte chunk l % 16 of the wave's 256 packed bytes (the slab's first row enters through the vector offset too:
+    // the scalar offset is outside the range check)
+    unsigned voP[NPS > 0 ? PS_PPW : 1];
+    if constexpr (NPS > 0) {
+#pragma unroll
+      for (int j = 0; j < PS_PPW; ++j) {
+        const int cw = 2 * pw + j / 4, q = j % 4;
+        voP[j] = (unsigned)((cw >> 1) * WTM + q * 4 + (lane >> 4)) * (unsigned)p.ldaux * 2u + (unsigned)(cw & 1) * 256u + (unsigned)(lane & 15) * 16u;
+      }
+    }
+    __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2, rsP;
     // descriptors of work unit `idx` of this block (idx < my_tiles: a tile of the walk; idx == my_tiles: the band item)
     auto set_unit = [&](int idx) __attribute__((always_inline)) {
       int m0, n0, rows;
@@ -171,10 +196,22 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       rsB = make_rsrc((const bf16_t*)p.B + (size_t)n0 * p.ldb, vn * (unsigned)p.ldb * 2u);
       rsA2 = make_rsrc(p.A2 ? (const bf16_t*)p.A2 + (size_t)m0 * p.lda2 : (const bf16_t*)p.A, p.A2 ? vm * (unsigned)p.lda2 * 2u : 0u);
       rsB2 = make_rsrc(p.B2 ? (const bf16_t*)p.B2 + (size_t)n0 * p.ldb2 : (const bf16_t*)p.B, p.B2 ? vn * (unsigned)p.ldb2 * 2u : 0u);
+      if constexpr (NPS > 0)     // saved pre-activation rows of this tile, from its first packed column (2 n0): rows beyond M read as zero
+        rsP = make_rsrc((const bf16_t*)p.aux + (size_t)m0 * p.ldaux + 2 * (size_t)n0, vm * (unsigned)p.ldaux * 2u);
     };
     // (generic lambda: the DMA builtin exists for the device target only, see gemm_kernel.hpp)
     auto issue = [&](int k, int stage, bool item, auto) __attribute__((always_inline)) {
       if (MVIT_WS_ABLATE & 1) return;
+      if constexpr (NPS > 0) {
+        if (k >= nk) {           // pseudo tile k - nk: the 16-row slab (k - nk) of every consumer wave
+          char* d = smem + stage * BUF_BYTES + pw * (2 * PS_WAVE_BYTES);
+          const unsigned slab = (unsigned)(k - nk) * 16u * (unsigned)p.ldaux * 2u;
+#pragma unroll
+          for (int j = 0; j < PS_PPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr)(d + j * 1024), 16, voP[j] + slab, 0, 0, 0);
+          return;
+        }
+      }
       char* b = smem + stage * BUF_BYTES + A_BYTES + pw * PB * 1024;
       const int soff = k < nk1 ? k * (BK * 2) : 0;
       // second K range (k >= nk1; LoRA: A2 = t [M, 2r], B2 = [N, 2r]): chunks at or beyond K2 are zero (OOB offsets above; K2 <= 64)
@@ -299,12 +336,14 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     bool l_item = my_tiles == 0;                          // the unit under the cursor is the band item (12 vs 6 pieces per request)
     if (G > 0) set_unit(0);
     bool last_item = false;                               // kind of the request made last (its pieces are what may stay in flight)
+    bool last_pseudo = false;
     auto issue_next = [&](auto tag) __attribute__((always_inline)) {
       issue(l_k, l_stage, l_item, tag);
       last_item = l_item;
+      last_pseudo = NPS > 0 && l_k >= nk;
       ++l_g;
       l_stage = l_stage + 1 == NSTAGE ? 0 : l_stage + 1;
-      if (++l_k == nk) {
+      if (++l_k == nks) {
         l_k = 0;
         ++l_unit;
         l_item = l_unit >= my_tiles;
@@ -315,6 +354,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     auto wait_older = [&]() __attribute__((always_inline)) {
       if (BAND && last_item)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PAQ + PB) : "memory");
+      else if (NPS > 0 && last_pseudo)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PS_PPW) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     };
@@ -330,7 +371,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     __builtin_amdgcn_s_barrier();                        // B(-1): K tile 0 has landed [no LDS reads pending]: producer waves never read LDS
     int g = 0;
     for (int t = 0; t < my_tiles + (has_item ? 1 : 0); ++t) {
-      for (int k = 0; k < nk; ++k, ++g) {
+      for (int k = 0; k < nks; ++k, ++g) {
         // stage (g + 2) % 3 = the one consumed in step g - 1: free since the barrier that ended it
         if (g + 2 < G) {
           issue_next(0);
@@ -340,7 +381,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         }
         __builtin_amdgcn_s_barrier();                    // B(g) [no LDS reads pending]: producer
       }
-      __builtin_amdgcn_s_barrier();                      // B'(unit): the consumers are done with the epilogue panel (= stage of step g - 1) [no LDS reads pending]: producer
+      if constexpr (NPS == 0)
+        __builtin_amdgcn_s_barrier();                    // B'(unit): the consumers are done with the epilogue panel (= stage of step g - 1) [no LDS reads pending]: producer
     }
     WS_STAMP(4, WS_CYC())
     WS_STAMP(5, WS_RT())
@@ -378,11 +420,11 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     if (m_base + wave_m * (16 * TMc) >= p.M) {
       // this wave's rows lie entirely beyond M (ragged last tile row: rows 192.. of a tile with 144 valid rows at M = 5264): it only
       // keeps the block's barriers -- no fragment reads, no MFMAs on zero rows (the loops are power-limited: work that is not done is clock)
-      for (int k = 0; k < nk; ++k) {
+      for (int k = 0; k < nks; ++k) {
         __builtin_amdgcn_s_barrier();                    // B(g) [no LDS reads pending]: a wave without rows reads nothing
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
       }
-      __builtin_amdgcn_s_barrier();                      // B'(unit) [no LDS reads pending]
+      if constexpr (NPS == 0) __builtin_amdgcn_s_barrier();   // B'(unit) [no LDS reads pending]
       return;
     }
     f32x4 acc[TMc][TN];
@@ -479,6 +521,66 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         __builtin_amdgcn_s_barrier();                        // B'(unit)
         return;
       }
+    }
+    if constexpr (NPS > 0 && TMc == 4) {
+      // ---- d(SwiGLU) on pseudo K tiles: `stage` names pseudo tile 0 (landed: the barrier inside the last K step published it).
+      // Step i: park the 16-row accumulator slab i, read it back row-wise with the slab's saved pre-activation from the stage,
+      // form d(silu(a) b) * dG, store; lgkmcnt(0) + the step's barrier release the stage.  No vector-memory load anywhere.
+      const int colw = n0 + wave_n * WTN, col = colw + lc;
+      const int ca = ((col >> 5) << 6) + (col & 31);           // packed position of gate columns col .. col + 7 (a; b at + 32)
+      const int k8 = lane & 7;
+      const unsigned pre_off = (unsigned)wave * PS_WAVE_BYTES + (unsigned)lr * 256u + (k8 < 4 ? 16u * k8 : 128u + 16u * (k8 - 4));
+#pragma unroll
+      for (int i = 0; i < NPS; ++i) {
+        const char* ps = smem + stage * BUF_BYTES;
+        float* pan = (float*)(wave < 4 ? smem + stage * BUF_BYTES + PS_BYTES + wave * PANEL_BYTES
+                                       : smem + NSTAGE * BUF_BYTES + (wave - 4) * PANEL_BYTES);
+        // park (C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + register); 16-byte chunk c of row r sits at
+        // chunk c ^ (r & 1): the row-wise b128 reads below then touch 16 distinct chunks per lane group
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = 4 * fh + r4;
+            pan[row * 64 + ((((4 * j + (fr >> 2)) ^ (r4 & 1))) << 2) + (fr & 3)] = acc[i][j][r4];     // (row & 1 == r4 & 1)
+          }
+#pragma unroll
+        for (int it = 0; it < NPASS; ++it) {
+          const int rl_ = it * RPP + lr;                       // RPP = 8: it * 8 + lane / 8
+          const int par = rl_ & 1;
+          const f32x4 t0 = *(const f32x4*)(pan + rl_ * 64 + (((2 * k8) ^ par) << 2));
+          const f32x4 t1 = *(const f32x4*)(pan + rl_ * 64 + (((2 * k8 + 1) ^ par) << 2));
+          const uint4 qa = *(const uint4*)(ps + pre_off + it * (RPP * 256));
+          const uint4 qb = *(const uint4*)(ps + pre_off + it * (RPP * 256) + 64);
+          const float v[V] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+          const uint32_t ua[4] = {qa.x, qa.y, qa.z, qa.w}, ub[4] = {qb.x, qb.y, qb.z, qb.w};
+          float da[V], db[V];
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const float a_ = (e & 1) ? __uint_as_float(ua[e >> 1] & 0xffff0000u) : __uint_as_float(ua[e >> 1] << 16);
+            const float b_ = (e & 1) ? __uint_as_float(ub[e >> 1] & 0xffff0000u) : __uint_as_float(ub[e >> 1] << 16);
+            const float sg = sigmoidf_(a_);
+            const float vs = v[e] * sg;
+            da[e] = vs * b_ * (1.f + a_ * (1.f - sg));
+            db[e] = vs * a_;
+          }
+          const int row = m_base + wave_m * WTM + i * 16 + rl_;
+          if (row < p.M) {
+            bf16_t* dst = Cb + (size_t)row * p.ldc + ca;
+            *(uint4*)dst = make_uint4(pack2bf(da[0], da[1]), pack2bf(da[2], da[3]), pack2bf(da[4], da[5]), pack2bf(da[6], da[7]));
+            *(uint4*)(dst + 32) = make_uint4(pack2bf(db[0], db[1]), pack2bf(db[2], db[3]), pack2bf(db[4], db[5]), pack2bf(db[6], db[7]));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the pseudo tile and of its panel are back
+        __builtin_amdgcn_s_barrier();                          // B(g): the stage may be refilled, the next step's tile has landed
+        __builtin_amdgcn_sched_barrier(0);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+      }
+#ifdef MVIT_WS_TIMING
+      if (units_done == 0) WS_STAMP(4, WS_CYC())
+      ++units_done;
+#endif
+      return;
     }
     // `stage` now names the first K tile of the NEXT output tile; the stage consumed last (every consumer is past its reads: the
     // barrier inside the last step) holds the epilogue panels until B'
@@ -667,7 +769,7 @@ bool ws_supported(const mvit_gemm_args& a) {
 template <int EPI, bool BAND>
 static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN);
-  const size_t lds = (size_t)ws::NSTAGE * ws::BUF_BYTES;
+  const size_t lds = (size_t)ws::NSTAGE * ws::BUF_BYTES + ((EPI == MVIT_EPI_DSWIGLU && !BAND) ? 4 * ws::PANEL_BYTES : 0);   // (+ panels of waves 4-7)
   int gx = gemm_num_cus();
   if (gx > tiles) gx = tiles;
   auto kern = ws::gemm_ws_kernel<EPI, BAND>;

@@ -162,3 +162,33 @@ def test_ws_single_round_residual_on_the_producer_waves(M, N, K):
         out4 = res.contiguous().clone()
         ops.gemm(a, b, out4, bias=bias, gamma=gam, epi=ops.EPI_RESID, flags=ops.OUT_F32)
         assert torch.equal(out4, out3)
+
+
+@pytest.mark.parametrize("M,H,K", [(5264, 4096, 1536), (5121, 512, 64), (5375, 1024, 128), (40000, 256, 192), (1024, 128, 64)])
+def test_ws_dswiglu_operand_on_pseudo_k_tiles(M, H, K):
+    """d(SwiGLU) epilogue with the saved pre-activation DMA'd into the operand ring as pseudo K tiles (csrc/gemm_ws.hip, round 5):
+    the benchmark's dfc2 shape (2.6 rounds of tiles), ragged last tile rows with 1 and 255 valid rows, many tiles per block with a
+    single K tile each (the ring then carries more pseudo tiles than real ones), guard rows behind the output, a padded leading
+    dimension of the saved tensor, run-to-run identity."""
+    import miphei_vit_amd.ops as ops
+    assert _is_ws(M, H, K, epi=ops.EPI_DSWIGLU)
+    g = torch.Generator(device="cuda").manual_seed(M + H + K)
+    dy, w2t = _rnd(g, M, K), _rnd(g, H, K, scale=K ** -0.5)
+    ldu = 2 * H + 64
+    ub = _rnd(g, M, ldu)
+    u = ub[:, :2 * H]
+    dub = torch.full((M + 4, 2 * H), 9.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dy, w2t, dub, M=M, aux=ub, ldaux=ldu, epi=ops.EPI_DSWIGLU)
+    uf = u.float().reshape(M, H // 32, 2, 32)
+    a_, b_ = uf[:, :, 0].reshape(M, H), uf[:, :, 1].reshape(M, H)
+    dG = dy.float() @ w2t.float().t()
+    sg = torch.sigmoid(a_)
+    da, db = dG * b_ * sg * (1 + a_ * (1 - sg)), dG * a_ * sg
+    ref = torch.stack([da.view(M, H // 32, 32), db.view(M, H // 32, 32)], dim=2).reshape(M, 2 * H)
+    assert _rel(dub[:M].float(), ref) < 6e-3
+    assert float((dub[M:].float() - 9.0).abs().max()) == 0.0
+    first = dub[:M].clone()
+    for _ in range(10):
+        dub.fill_(9.0)
+        ops.gemm(dy, w2t, dub, M=M, aux=ub, ldaux=ldu, epi=ops.EPI_DSWIGLU)
+        assert torch.equal(dub[:M], first)

@@ -1,0 +1,18 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+O=gpurun_out/r05_run6
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gemm_ws_gpu.py -x -q > $O/pytest.log 2>&1
+echo "pytest rc $?" >> $O/pytest.log
+WS_TIMING_ONLY=dfc2+dswiglu MIPHEI_LIB=miphei-vit_amd/libmiphei_tm.so timeout 300 python tools/ws_timing.py > $O/ws_timing_dswiglu.txt 2>&1
+timeout 300 python tools/bench_epi.py > $O/epi.txt 2>&1
+for r in 1 2; do
+  for v in prev hip_dbg; do
+    echo "lib $v" >> $O/ab.txt
+    MIPHEI_LIB=miphei-vit_amd/libmiphei_$v.so timeout 600 python tools/bench_lib.py --no-cpu-baseline --steps 30 --warmup 8 --probe 0 --comm-standin 0 2>> $O/ab.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])" >> $O/ab.txt
+  done
+done
+timeout 1200 python -m pytest tests/test_training_gpu.py tests/test_generator_gpu.py tests/test_deterministic_gpu.py tests/test_full_size_gpu.py -x -q > $O/pytest_model.log 2>&1
+echo "pytest rc $?" >> $O/pytest_model.log
+tail -5 $O/pytest.log; grep -v amdgpu.ids $O/ws_timing_dswiglu.txt | cut -c1-330; grep -v amdgpu.ids $O/epi.txt; cat $O/ab.txt; tail -4 $O/pytest_model.log
