@@ -207,8 +207,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           char* d = smem + stage * BUF_BYTES + pw * (2 * PS_WAVE_BYTES);
           const unsigned slab = (unsigned)(k - nk) * 16u * (unsigned)p.ldaux * 2u;
 #pragma unroll
-          for (int j = 0; j < PS_PPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr)(d + j * 1024), 16, voP[j] + slab, 0, 0, 0);
+          for (int j = 0; j < PS_PPW; ++j) {
+            const unsigned off = voP[j] + slab;   // (a local on purpose: with the expression as the builtin's argument the host pass of hipcc silently drops the kernel's stub)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr)(d + j * 1024), 16, off, 0, 0, 0);
+          }
           return;
         }
       }

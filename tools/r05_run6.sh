@@ -3,6 +3,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/r05_run6
 mkdir -p $O
 export TMPDIR=/tmp
+for l in hip hip_dbg tm prev; do python -c "import ctypes; ctypes.CDLL('miphei-vit_amd/libmiphei_$l.so')" || { echo "lib $l does not load"; exit 9; }; done
 timeout 900 python -m pytest tests/test_gemm_ws_gpu.py -x -q > $O/pytest.log 2>&1
 echo "pytest rc $?" >> $O/pytest.log
 WS_TIMING_ONLY=dfc2+dswiglu MIPHEI_LIB=miphei-vit_amd/libmiphei_tm.so timeout 300 python tools/ws_timing.py > $O/ws_timing_dswiglu.txt 2>&1
