@@ -66,8 +66,7 @@ struct AttnDims {
   // unit in front of everything else (profiles/r04_attn_timing.txt: 17 % of a wave's cycles before its first tile step).
   unsigned nx, nx_magic, h_magic;
 };
-// floor(x / d) for x < 2^32 / d: mulhi(x, floor(2^32 / d) + 1); d == 1 has no 32-bit constant
-__device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
+__device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned magic) { return mvit_fast_div(x, d, magic); }   // (common.hpp)
 
 // DMA one 64-row x 64-col bf16 tile (rows row0.. of a matrix with row stride `rs` elements) straight into LDS
 // (buffer_load ... lds, 16 B per lane): lane l of a wave fills row l>>3, 16-byte slot l&7 of 8 consecutive rows; the
@@ -686,7 +685,7 @@ static bool make_dims(AttnDims& dm, int B, int N, int H, int Dh, float scale) {
   const unsigned long long total = (unsigned long long)nx * (unsigned)B * (unsigned)H;
   const unsigned dmax = nx > (unsigned)H ? nx : (unsigned)H;
   if (total * dmax >= 0xffffffffull) return false;           // (fast_div's range; also keeps the 1-D grid far below its limit)
-  dm = AttnDims{B, N, H, Dh, scale, nx, (unsigned)(0x100000000ull / nx) + 1u, (unsigned)(0x100000000ull / (unsigned)H) + 1u};
+  dm = AttnDims{B, N, H, Dh, scale, nx, mvit_div_magic(nx), mvit_div_magic((unsigned)H)};
   return true;
 }
 

@@ -50,6 +50,12 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// floor(x / d) without a division instruction sequence: mulhi(x, floor(2^32 / d) + 1), exact for x < 2^32 / d; d == 1 has no 32-bit
+// constant.  A division by a run-time value costs a wave ~25 instructions and two trips through the vector unit (v_rcp_iflag +
+// readfirstlane); in a kernel prologue every wave of the CU runs it at once on the CU's one scalar unit.
+__device__ __forceinline__ unsigned mvit_fast_div(unsigned x, unsigned d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
+static inline unsigned mvit_div_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / d) + 1u; }
+
 // Host-side per-device state.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are properties of the CURRENT
 // device, so anything cached about them is keyed by hipGetDevice() (a process may drive several GPUs, from several threads).
 // Relaxed atomics are enough: the cached value only ever grows and re-applying an attribute is idempotent.

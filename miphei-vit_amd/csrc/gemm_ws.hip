@@ -88,8 +88,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
                                            (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// host-built constants of the block map (round 5: no run-time integer division in the prologue -- tools/ws_timing.py: ~2000 cycles
+// from kernel entry to the first operand request, three divisions among them)
+struct WsExtra {
+  unsigned grid_magic;       // mvit_div_magic(gridDim.x)
+  unsigned pg_magic;         // mvit_div_magic(GROUP_M * tiles_n), tiles_n = N / BN (band mode: same tiles_n)
+};
+// x / g for the group heights 1 .. 4
+__device__ __forceinline__ int div_small(int x, int g) {
+  return g == 4 ? x >> 2 : g == 2 ? x >> 1 : g == 1 ? x : (int)__umulhi((unsigned)x, 0x55555556u);
+}
 struct TileOrder {   // virtual tile id -> XCD-aware, grouped (8 tile rows x all columns) coordinates, as gemm_kernel.hpp
   int tiles_m, tiles_n, ntiles;
+  unsigned pg_magic;
   __device__ __forceinline__ void get(int vt, int& m0, int& n0) const {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = vt & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vt >> 3);
@@ -97,18 +108,22 @@ struct TileOrder {   // virtual tile id -> XCD-aware, grouped (8 tile rows x all
 #define MVIT_WS_GROUP_M 4
 #endif
     constexpr int GROUP_M = MVIT_WS_GROUP_M;   // tile rows per group of the walk: an XCD's 32 concurrent tiles are a 4 x 8 patch (4 A panels + 8 B panels per K tile = the least L2-miss bytes); same-box step 482.4 / 481.2 (4) vs 477.7 / 475.4 (8) vs 464.1 / 463.2 (16) tiles/s
+    static_assert(GROUP_M <= 4, "div_small covers group heights 1 .. 4");
     const int per_group = GROUP_M * tiles_n;
-    const int first_m = (wg / per_group) * GROUP_M;
+    const int grp = (int)mvit_fast_div((unsigned)wg, (unsigned)per_group, pg_magic);
+    const int first_m = grp * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
-    m0 = (first_m + (wg % per_group) % gsz) * BM;
-    n0 = ((wg % per_group) / gsz) * BN;
+    const int in_grp = wg - grp * per_group;
+    const int cg = div_small(in_grp, gsz);
+    m0 = (first_m + (in_grp - cg * gsz)) * BM;
+    n0 = cg * BN;
   }
 };
 
 // BAND: the kernel also takes the 64-row items of the ragged band (see the work plan below); instantiated for the epilogues whose
 // shapes need it (store, SwiGLU) -- the residual kernel sits at 168 VGPRs without it
 template <int EPI, bool BAND>
-__global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_gemm_args p) {
+__global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_gemm_args p, const WsExtra xp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,14 +139,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   ord.tiles_m = band ? p.M / BM : (p.M + BM - 1) / BM;
   ord.tiles_n = p.N / BN;
   ord.ntiles = ord.tiles_m * ord.tiles_n;
+  ord.pg_magic = xp.pg_magic;
   const int nk1 = p.K / BK;
   const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
   const int nk = nk1 + nk2;
   constexpr int NPS = (EPI == MVIT_EPI_DSWIGLU && !BAND) ? NPSEUDO : 0;   // pseudo K tiles behind every unit's real ones
   const int nks = nk + NPS;                                                // ring steps per unit
-  const int my_tiles = ((int)blockIdx.x < ord.ntiles) ? (ord.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int my_tiles = ((int)blockIdx.x < ord.ntiles) ? (int)mvit_fast_div((unsigned)(ord.ntiles - 1 - (int)blockIdx.x), gridDim.x, xp.grid_magic) + 1 : 0;
   const bool has_item = BAND && (int)blockIdx.x < nq * ord.tiles_n;                // band item of this block: column bx / nq, quarter bx % nq
-  const int item_m = rows_full + ((int)blockIdx.x % (nq > 0 ? nq : 1)) * 64, item_n = ((int)blockIdx.x / (nq > 0 ? nq : 1)) * BN;
+  const int item_col = div_small((int)blockIdx.x, nq > 0 ? nq : 1);                // (nq <= 4: the band is lower than a tile)
+  const int item_m = rows_full + ((int)blockIdx.x - item_col * (nq > 0 ? nq : 1)) * 64, item_n = item_col * BN;
   const int G = (my_tiles + (has_item ? 1 : 0)) * nks;  // ring steps this block walks (global step index g)
 #ifdef MVIT_WS_TIMING
   long long* prof = p.stats ? (long long*)p.stats + (size_t)blockIdx.x * 16 + (wave >= NCW ? 8 : 0) : nullptr;
@@ -561,10 +578,15 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           for (int e = 0; e < V; ++e) {
             const float a_ = (e & 1) ? __uint_as_float(ua[e >> 1] & 0xffff0000u) : __uint_as_float(ua[e >> 1] << 16);
             const float b_ = (e & 1) ? __uint_as_float(ub[e >> 1] & 0xffff0000u) : __uint_as_float(ub[e >> 1] << 16);
+#ifdef MVIT_WS_DSW_NOMATH      // measurement build (results are garbage): the epilogue without the sigmoid algebra
+            da[e] = v[e] * a_;
+            db[e] = v[e] * b_;
+#else
             const float sg = sigmoidf_(a_);
             const float vs = v[e] * sg;
             da[e] = vs * b_ * (1.f + a_ * (1.f - sg));
             db[e] = vs * a_;
+#endif
           }
           const int row = m_base + wave_m * WTM + i * 16 + rl_;
           if (row < p.M) {
@@ -762,6 +784,11 @@ bool ws_supported(const mvit_gemm_args& a) {
   if (a.epi == MVIT_EPI_RESID && (!(a.flags & MVIT_OUT_F32) || a.rowscale)) return false;   // (DropPath row factors: 8 more registers than the 168 this kernel has)
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_RESID && (a.flags & MVIT_OUT_F32)) return false;
   if (a.epi != MVIT_EPI_STORE && (a.flags & MVIT_ACCUM_BF16)) return false;
+  // mvit_fast_div: tile index x divisor below 2^32 (tiles < 2^20 at these sizes; checked, not assumed)
+  {
+    const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 128), pg = 4ll * (a.N / 128);
+    if (tiles * (pg > 256 ? pg : 256) >= 0xffffffffll) return false;
+  }
   // 32-bit byte offsets inside a tile's descriptor range
   const long long maxld = a.lda > a.ldb ? a.lda : a.ldb;
   if (256ll * maxld * 2 >= 0x7fffffffll) return false;
@@ -777,7 +804,10 @@ static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   auto kern = ws::gemm_ws_kernel<EPI, BAND>;
   static mvit_per_device_size raised;
   if (mvit_ensure_dynamic_lds((const void*)kern, lds, raised) != MVIT_OK) return MVIT_EINVAL;
-  hipLaunchKernelGGL(kern, dim3(gx), dim3(64 * (ws::NCW + ws::NPW)), lds, s, a);
+  ws::WsExtra xp;
+  xp.grid_magic = mvit_div_magic((unsigned)gx);
+  xp.pg_magic = mvit_div_magic((unsigned)(MVIT_WS_GROUP_M * (a.N / ws::BN)));
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(64 * (ws::NCW + ws::NPW)), lds, s, a, xp);
   return MVIT_LAUNCH_CHECK();
 }
 
