@@ -186,18 +186,29 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       voB[j] = (unsigned)row * (unsigned)p.ldb * 2u + (unsigned)cs * 16u;
       voB2[j] = (cs * 8 < p.K2) ? (unsigned)row * (unsigned)p.ldb2 * 2u + (unsigned)cs * 16u : OOB;
     }
+    // d(SwiGLU) instantiation: the same offsets as two per-lane bases (even / odd piece: the swizzle term (row >> 1) & 7 only depends
+    // on the piece's parity) + a uniform step per piece pair -- 4 registers instead of 12, the rest go to the operand prefetch
+    constexpr bool COMPACT = EPI == MVIT_EPI_DSWIGLU;
+    const unsigned stepA = 16u * (unsigned)p.lda * 2u, stepB = 16u * (unsigned)p.ldb * 2u;
+    // (the step passes through an empty asm at every use: otherwise the adds are hoisted out of the step loop into eight registers again)
+    auto opaque = [&](unsigned v) __attribute__((always_inline)) { asm volatile("" : "+s"(v)); return v; };
+    auto offA = [&](int j) __attribute__((always_inline)) { return COMPACT ? voA[j & 1] + (unsigned)(j >> 1) * opaque(stepA) : voA[j]; };
+    auto offB = [&](int j) __attribute__((always_inline)) { return COMPACT ? voB[j & 1] + (unsigned)(j >> 1) * opaque(stepB) : voB[j]; };
     // pseudo tiles: piece j of this wave = rows 4 q .. 4 q + 3 (q = j % 4) of consumer wave cw = 2 pw + j / 4's slab; lane l holds
     // row l / 16, 16-byte chunk l % 16 of the wave's 256 packed bytes (the slab's first row enters through the vector offset too:
     // the scalar offset is outside the range check)
-    unsigned voP[NPS > 0 ? PS_PPW : 1];
+    // (kept as two per-lane bases + a uniform row step: 2 registers instead of 8 -- the operand prefetch below needs them)
+    unsigned voPb[2] = {0u, 0u};
+    const unsigned voPq = 4u * (unsigned)p.ldaux * 2u;
     if constexpr (NPS > 0) {
 #pragma unroll
-      for (int j = 0; j < PS_PPW; ++j) {
-        const int cw = 2 * pw + j / 4, q = j % 4;
-        voP[j] = (unsigned)((cw >> 1) * WTM + q * 4 + (lane >> 4)) * (unsigned)p.ldaux * 2u + (unsigned)(cw & 1) * 256u + (unsigned)(lane & 15) * 16u;
+      for (int c = 0; c < 2; ++c) {
+        const int cw = 2 * pw + c;
+        voPb[c] = (unsigned)((cw >> 1) * WTM + (lane >> 4)) * (unsigned)p.ldaux * 2u + (unsigned)(cw & 1) * 256u + (unsigned)(lane & 15) * 16u;
       }
     }
-    __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2, rsP;
+    auto voP = [&](int j) __attribute__((always_inline)) { unsigned q_ = voPq; asm volatile("" : "+s"(q_)); return voPb[j / 4] + (unsigned)(j % 4) * q_; };
+    __amdgpu_buffer_rsrc_t rsA, rsB, rsA2, rsB2, rsP, rsPcur;
     // descriptors of work unit `idx` of this block (idx < my_tiles: a tile of the walk; idx == my_tiles: the band item)
     auto set_unit = [&](int idx) __attribute__((always_inline)) {
       int m0, n0, rows;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           const unsigned slab = (unsigned)(k - nk) * 16u * (unsigned)p.ldaux * 2u;
 #pragma unroll
           for (int j = 0; j < PS_PPW; ++j) {
-            const unsigned off = voP[j] + slab;   // (a local on purpose: with the expression as the builtin's argument the host pass of hipcc silently drops the kernel's stub)
+            const unsigned off = voP(j) + slab;   // (a local on purpose: with the expression as the builtin's argument the host pass of hipcc silently drops the kernel's stub)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr)(d + j * 1024), 16, off, 0, 0, 0);
           }
           return;
@@ -233,12 +244,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       }
       char* b = smem + stage * BUF_BYTES + A_BYTES + pw * PB * 1024;
       const int soff = k < nk1 ? k * (BK * 2) : 0;
+      constexpr bool HAS_K2 = EPI != MVIT_EPI_DSWIGLU;      // (d(SwiGLU) never carries a second K range: ws_supported; its registers go to the operand prefetch)
       // second K range (k >= nk1; LoRA: A2 = t [M, 2r], B2 = [N, 2r]): chunks at or beyond K2 are zero (OOB offsets above; K2 <= 64)
       if (!BAND || !item) {
         char* a = smem + stage * BUF_BYTES + pw * PA * 1024;
-        if (k < nk1) {
+        if (!HAS_K2 || k < nk1) {
 #pragma unroll
-          for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 1024), 16, voA[j], soff, 0, 0);
+          for (int j = 0; j < PA; ++j) {
+            const unsigned off = offA(j);    // (a local: see the note at the pseudo-tile requests)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a + j * 1024), 16, off, soff, 0, 0);
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 1024), 16, voA2[j], 0, 0, 0);
@@ -253,9 +268,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           for (int j = 0; j < PAQ; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a + j * 1024), 16, voAq2[j], 0, 0, 0);
         }
       }
-      if (k < nk1) {
+      if (!HAS_K2 || k < nk1) {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * 1024), 16, voB[j], soff, 0, 0);
+        for (int j = 0; j < PB; ++j) {
+          const unsigned off = offB(j);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(b + j * 1024), 16, off, soff, 0, 0);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(b + j * 1024), 16, voB2[j], 0, 0, 0);
@@ -344,6 +362,112 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           for (int e = 0; e < 4; ++e) o[e] = r[e] + gam4[e] * (a[e] + bias4[e]);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, co, 0, 0);
           co += cstep;
+        }
+        WS_STAMP(4, WS_CYC())
+        WS_STAMP(5, WS_RT())
+        return;
+      }
+    }
+    if constexpr (NPS > 0) {
+      constexpr int PRE_STEPS = NPS * PS_PPW / RES_PER_STEP;        // 32 requests of 16 bytes per lane, 4 per step: the first 8 steps of a unit
+      if ((p.flags & 0x8000) && nk >= PRE_STEPS + 2) {
+        // ---- d(SwiGLU), operand prefetched into the producers' registers (round 5).  The DMA form above requests a pseudo tile two
+        // ring steps ahead: that hides the latency of the saved pre-activation but not its VOLUME -- 256 blocks reach their
+        // epilogues together and ask for 32 MB within a few microseconds (tools/ws_timing.py: the epilogue took 13.4 k cycles per
+        // tile with or without the sigmoid algebra, with the operand loaded by the consumers or DMA'd two steps ahead).  Here a
+        // producer wave requests its share of the tile's operand (8 KB per slab, 32 x 16 bytes per lane = 128 registers it never
+        // uses otherwise) during the first PRE_STEPS K steps of the tile, behind each step's operand DMA, and writes slab s into the
+        // ring with ds_write at the step where the DMA form would have issued pseudo tile s: the 128 KB per tile now cross the
+        // fabric spread over the whole K loop.  Consumers, ring protocol and LDS image are those of the DMA form.
+        u32x4 pre[NPS * PS_PPW];
+        int l_unit = 0, l_k = 0, l_stage = 0, l_g = 0;
+        set_unit(0);
+        auto advance = [&]() __attribute__((always_inline)) {
+          ++l_g;
+          l_stage = l_stage + 1 == NSTAGE ? 0 : l_stage + 1;
+          if (++l_k == nks) {
+            l_k = 0;
+            ++l_unit;
+            if (l_g < G) set_unit(l_unit);
+          }
+        };
+        auto wait_allow = [&](int n) __attribute__((always_inline)) {       // at most n requests younger than what must have landed
+          if (n >= PPW + 2 * RES_PER_STEP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * RES_PER_STEP) : "memory");
+          else if (n >= PPW + RES_PER_STEP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + RES_PER_STEP) : "memory");
+          else if (n >= PPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+          else if (n >= 2 * RES_PER_STEP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RES_PER_STEP) : "memory");
+          else if (n >= RES_PER_STEP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RES_PER_STEP) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        issue(l_k, l_stage, false, 0);
+        advance();
+        WS_STAMP(2, WS_CYC())
+        issue(l_k, l_stage, false, 0);
+        advance();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        WS_STAMP(3, WS_CYC())
+        __builtin_amdgcn_s_barrier();                    // B(-1) [no LDS reads pending]: producer
+        int g = 0, r_prev = 0;
+        static_assert(PRE_STEPS == 8 && RES_PER_STEP * 2 == PS_PPW, "load steps are written out for 8 steps of 4 requests");
+        // One ring step of the unit under consumption.  KC >= 0: load step KC (the look-ahead request is a real K tile, then four
+        // operand requests of THIS unit into pre[4 KC ..]); SL >= 0: the look-ahead request is pseudo tile SL (ds_write from
+        // pre[8 SL ..]); both -1: a plain step (real K tile of this or of the next unit).  Every register index is a literal.
+        auto step = [&](auto kc_tag, auto sl_tag, auto tag) __attribute__((always_inline)) {
+          constexpr int KC = decltype(kc_tag)::value, SL = decltype(sl_tag)::value;
+          const bool req = g + 2 < G;
+          int pieces = 0, r_cur = 0;
+          if constexpr (SL >= 0) {
+            // (the cursor stands on pseudo tile SL of the unit under consumption: always inside the walk)
+            char* d = smem + l_stage * BUF_BYTES + pw * (2 * PS_WAVE_BYTES) + lane * 16;
+#pragma unroll
+            for (int j = 0; j < PS_PPW; ++j) *(u32x4*)(d + j * 1024) = pre[SL * PS_PPW + j];
+            advance();
+          } else if (req) {
+            issue(l_k, l_stage, false, tag);
+            advance();
+            pieces = PPW;
+          }
+          if constexpr (KC >= 0) {
+            const unsigned slab = (unsigned)(KC / 2) * 16u * (unsigned)p.ldaux * 2u;
+#pragma unroll
+            for (int j = 0; j < RES_PER_STEP; ++j) {
+              const unsigned off = voP((KC % 2) * RES_PER_STEP + j) + slab;
+              pre[KC * RES_PER_STEP + j] = __builtin_amdgcn_raw_buffer_load_b128(rsPcur, off, 0, 0);
+            }
+            r_cur = RES_PER_STEP;
+          }
+          // in flight, oldest first: request of step g + 1 | operand loads of step g - 1 | request of step g + 2 | operand loads of step g
+          if (req || SL >= 0) wait_allow(r_prev + pieces + r_cur);
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (SL >= 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab is in LDS before a later barrier publishes it
+          __builtin_amdgcn_s_barrier();                  // B(g) [no LDS reads pending]: producer (its ds_writes were waited for above)
+          r_prev = r_cur;
+          ++g;
+        };
+        using N1 = std::integral_constant<int, -1>;
+        for (int t = 0; t < my_tiles; ++t) {
+          // descriptor of the unit under CONSUMPTION (the cursor's rsP is already two steps ahead at a unit's end)
+          {
+            int m0, n0;
+            ord.get(blockIdx.x + t * gridDim.x, m0, n0);
+            const unsigned vm = (unsigned)min(BM, p.M - m0);
+            rsPcur = make_rsrc((const bf16_t*)p.aux + (size_t)m0 * p.ldaux + 2 * (size_t)n0, vm * (unsigned)p.ldaux * 2u);
+          }
+          step(std::integral_constant<int, 0>{}, N1{}, 0);
+          step(std::integral_constant<int, 1>{}, N1{}, 0);
+          step(std::integral_constant<int, 2>{}, N1{}, 0);
+          step(std::integral_constant<int, 3>{}, N1{}, 0);
+          step(std::integral_constant<int, 4>{}, N1{}, 0);
+          step(std::integral_constant<int, 5>{}, N1{}, 0);
+          step(std::integral_constant<int, 6>{}, N1{}, 0);
+          step(std::integral_constant<int, 7>{}, N1{}, 0);
+          for (int k = PRE_STEPS; k < nk - 2; ++k) step(N1{}, N1{}, 0);           // the look-ahead request is K tile k + 2 < nk
+          step(N1{}, std::integral_constant<int, 0>{}, 0);                          // steps nk - 2 .. nk + 1: pseudo tiles 0 .. 3
+          step(N1{}, std::integral_constant<int, 1>{}, 0);
+          step(N1{}, std::integral_constant<int, 2>{}, 0);
+          step(N1{}, std::integral_constant<int, 3>{}, 0);
+          step(N1{}, N1{}, 0);                                                      // steps nk + 2, nk + 3: the next unit's K tiles 0 and 1
+          step(N1{}, N1{}, 0);
         }
         WS_STAMP(4, WS_CYC())
         WS_STAMP(5, WS_RT())
@@ -777,10 +901,11 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 
 // problems the wave-specialised kernel takes (everything else stays on gemm_kernel.hpp)
 bool ws_supported(const mvit_gemm_args& a) {
-  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000 | 0x4000))) return false;
+  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000 | 0x4000 | 0x8000))) return false;
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_SWIGLU && a.epi != MVIT_EPI_RESID && a.epi != MVIT_EPI_DSWIGLU) return false;
   if (a.M < 1024 || (a.N % 128) || (a.K % 64) || a.K < 64) return false;
   if (a.A2 && (a.K2 > 64 || a.K2 <= 0)) return false;
+  if (a.A2 && a.epi == MVIT_EPI_DSWIGLU) return false;
   if (a.epi == MVIT_EPI_RESID && (!(a.flags & MVIT_OUT_F32) || a.rowscale)) return false;   // (DropPath row factors: 8 more registers than the 168 this kernel has)
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_RESID && (a.flags & MVIT_OUT_F32)) return false;
   if (a.epi != MVIT_EPI_STORE && (a.flags & MVIT_ACCUM_BF16)) return false;
@@ -823,9 +948,9 @@ bool ws_band_mode(const mvit_gemm_args& a) {
   return rounds_full < rounds_all && (rf * nt) % cus == 0 && items <= cus;
 }
 
-int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_single_knob) {
+int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob) {
   mvit_gemm_args a = a0;
-  a.flags &= ~(0x2000 | 0x4000);
+  a.flags &= ~(0x2000 | 0x4000 | 0x8000);
   if (band_knob && ws_band_mode(a)) {
     a.flags |= 0x2000;
     return a.epi == MVIT_EPI_STORE ? launch_ws_one<MVIT_EPI_STORE, true>(a, s) : launch_ws_one<MVIT_EPI_SWIGLU, true>(a, s);
@@ -834,6 +959,7 @@ int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_
   if (a.epi == MVIT_EPI_RESID && resid_single_knob && (long long)((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN) <= gemm_num_cus() &&
       a.K / ws::BK >= ws::RES_STEPS + 3 && !a.A2)
     a.flags |= 0x4000;
+  if (a.epi == MVIT_EPI_DSWIGLU && dsw_reg_knob) a.flags |= 0x8000;     // operand of the d(SwiGLU) epilogue through the producers' registers
   switch (a.epi) {
     case MVIT_EPI_STORE: return launch_ws_one<MVIT_EPI_STORE, false>(a, s);
     case MVIT_EPI_SWIGLU: return launch_ws_one<MVIT_EPI_SWIGLU, false>(a, s);
