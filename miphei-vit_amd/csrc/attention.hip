@@ -719,4 +719,27 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* ou
   return MVIT_LAUNCH_CHECK();
 }
 
+#ifdef MVIT_DEBUG_KNOBS
+// measurement library only (make dbg): the two backward kernels as separate launches, so that tools/attn_overlap.py can put them on
+// two streams (the dK/dV kernel reads the D vector the dQ kernel writes: the tool keeps a D from an earlier serial run)
+MVIT_API int mvit_attention_bwd_part(int which, const void* qkv, const void* out, const void* out_res, const void* d_out, const float* lse,
+                                     float* dsum, void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream) {
+  MVIT_CLEAR_ERROR();
+  AttnDims dm;
+  if (!make_dims(dm, B, N, H, Dh, scale)) return MVIT_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (which == 0) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
+                       (const bf16_t*)out, (const bf16_t*)out_res, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
+  } else {
+    const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;
+    static mvit_per_device_size lds_raised;
+    if (mvit_ensure_dynamic_lds((const void*)attn_bwd_dkv_kernel, lds_kv, lds_raised) != MVIT_OK) return MVIT_EINVAL;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), lds_kv, s, (const bf16_t*)qkv,
+                       (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
+  }
+  return MVIT_LAUNCH_CHECK();
+}
+#endif
+
 }  // extern "C"
