@@ -1,11 +1,11 @@
 #!/bin/bash
 # Measurement pass on the GPU box: every bench line DESIGN.md quotes, the rocprofv3 kernel statistics and the two PMC passes of
 # the headline command.  Writes gpurun_out/<tag>/ (scratch) and, with COPY=1 (default), the summaries into profiles/<round>_*.
-#   gpurun --timeout 1800 -- 'bash tools/bench_all.sh r04'
+#   gpurun --timeout 1800 -- 'bash tools/bench_all.sh r05'
 # Every line is produced by bench.py itself (one JSON object per file), so a claim in DESIGN.md can be re-run verbatim.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O profiles
+R=${1:-r05}; O=gpurun_out/$R; mkdir -p $O profiles
 run() { out=$1; shift; python3 bench.py "$@" > $O/$out.json 2> $O/$out.err || echo "FAILED: $out" >&2; }
 run bench_train                                                                    # BASELINE configs[1], the driver's command
 run bench_train_metrics_on --metrics 1 --no-cpu-baseline
