@@ -7,7 +7,7 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s);
 namespace mvit_gemm {
 int gemm_num_cus() { return mvit_num_cus(); }
 bool ws_supported(const mvit_gemm_args& a);           // gemm_ws.hip: the wave-specialised 256x128 kernel (round 4)
-int launch_ws(const mvit_gemm_args& a, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob);
+int launch_ws(const mvit_gemm_args& a, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob, int pack_store_knob);
 }  // namespace mvit_gemm
 
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
@@ -118,7 +118,8 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   MVIT_KNOB(ws_band, "MVIT_GEMM_WS_BAND", 1);     // 0: the ragged last tile row always as whole 256-row tiles (measurement)
   MVIT_KNOB(ws_rsingle, "MVIT_GEMM_WS_RSINGLE", 1);   // 0: one-round residual GEMMs keep the consumer-side epilogue (measurement)
   MVIT_KNOB(ws_dswreg, "MVIT_GEMM_WS_DSWREG", 1);     // 0: the d(SwiGLU) operand as DMA'd pseudo tiles (two steps ahead) instead of the register prefetch
-  if (takes_ws(a, v)) return launch_ws(a, s, ws_band, ws_rsingle, ws_dswreg);
+  MVIT_KNOB(ws_packst, "MVIT_GEMM_WS_PACKST", 1);     // 0: plain bf16 stores through the f32 panel (measurement)
+  if (takes_ws(a, v)) return launch_ws(a, s, ws_band, ws_rsingle, ws_dswreg, ws_packst);
 #ifdef MVIT_DEBUG_KNOBS
   if (v == id(256, 256, 2, 2)) return launch_dense<256, 256, 2, 2>(a, s);
   if (v == id(256, 128, 2, 2)) return launch_dense<256, 128, 2, 2>(a, s);

@@ -736,6 +736,48 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     float* stg = (float*)(smem + last * BUF_BYTES) + (size_t)wave * SLAB;
 
     // ---------------------------------------------------------------- epilogue (vector paths only: N % 128 == 0, aligned operands)
+    if constexpr (EPI == MVIT_EPI_STORE) {
+      if (!out_f32 && !(p.flags & MVIT_ACCUM_BF16) && !(p.flags & 0x10000)) {
+        // Plain bf16 store through a HALF-SIZE panel (round 5).  The f32 panel epilogue is LDS-write bound: 8 waves park 128 KB per
+        // tile at 64 B/clk (tools/ws_timing.py: 3.1 k cycles per tile).  A lane's four accumulator registers of a 16x16 block are four
+        // consecutive ROWS of one column, so rows (2 P, 2 P + 1) round to bf16 and share one dword: 32 ds_write_b32 per lane
+        // instead of 64; a lane reads 8 such dwords back (8 columns x 2 rows), splits low / high halves with v_perm and stores one
+        // 16-byte group per row.  Bias is added before the rounding, as in the f32 form (same bits).
+        constexpr int SLDW = WTN + 4;                              // panel row (one row PAIR) in dwords
+        uint32_t* stgw = (uint32_t*)(smem + last * BUF_BYTES) + (size_t)wave * (8 * SLDW);
+        const int colw = n0 + wave_n * WTN;
+        float bc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bc[j] = p.bias ? p.bias[colw + j * 16 + fr] : 0.f;
+        const int P = lane >> 3, k8 = lane & 7;
+#pragma unroll
+        for (int i = 0; i < TMc; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              stgw[(2 * fh + h) * SLDW + j * 16 + fr] = pack2bf(acc[i][j][2 * h] + bc[j], acc[i][j][2 * h + 1] + bc[j]);
+          if (i == 0) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the bias loads (from here on only stores are pending)
+          const uint4 t0 = *(const uint4*)(stgw + P * SLDW + k8 * 8), t1 = *(const uint4*)(stgw + P * SLDW + k8 * 8 + 4);
+          // low halves = row 2 P, high halves = row 2 P + 1 (v_perm_b32 selectors: bytes 0,1 of both / bytes 2,3 of both)
+          const uint4 lo = make_uint4(__builtin_amdgcn_perm(t0.y, t0.x, 0x05040100u), __builtin_amdgcn_perm(t0.w, t0.z, 0x05040100u),
+                                      __builtin_amdgcn_perm(t1.y, t1.x, 0x05040100u), __builtin_amdgcn_perm(t1.w, t1.z, 0x05040100u));
+          const uint4 hi = make_uint4(__builtin_amdgcn_perm(t0.y, t0.x, 0x07060302u), __builtin_amdgcn_perm(t0.w, t0.z, 0x07060302u),
+                                      __builtin_amdgcn_perm(t1.y, t1.x, 0x07060302u), __builtin_amdgcn_perm(t1.w, t1.z, 0x07060302u));
+          const int row = m_base + wave_m * (16 * TMc) + i * 16 + 2 * P;
+          bf16_t* dst = Cb + (size_t)row * p.ldc + colw + k8 * 8;
+          if (row < p.M) *(uint4*)dst = lo;
+          if (row + 1 < p.M) *(uint4*)(dst + p.ldc) = hi;
+        }
+#ifdef MVIT_WS_TIMING
+        if (units_done == 0) WS_STAMP(4, WS_CYC())
+        ++units_done;
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (panel reads finished: the producers refill this stage behind B')
+        __builtin_amdgcn_s_barrier();                              // B'(unit)
+        return;
+      }
+    }
     const int colw = n0 + wave_n * WTN;
     const int col = colw + lc;
     float bias[V], bias2[V], gam[V];
@@ -901,7 +943,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 
 // problems the wave-specialised kernel takes (everything else stays on gemm_kernel.hpp)
 bool ws_supported(const mvit_gemm_args& a) {
-  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000 | 0x4000 | 0x8000))) return false;
+  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000 | 0x4000 | 0x8000 | 0x10000))) return false;
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_SWIGLU && a.epi != MVIT_EPI_RESID && a.epi != MVIT_EPI_DSWIGLU) return false;
   if (a.M < 1024 || (a.N % 128) || (a.K % 64) || a.K < 64) return false;
   if (a.A2 && (a.K2 > 64 || a.K2 <= 0)) return false;
@@ -948,9 +990,9 @@ bool ws_band_mode(const mvit_gemm_args& a) {
   return rounds_full < rounds_all && (rf * nt) % cus == 0 && items <= cus;
 }
 
-int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob) {
+int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob, int pack_store_knob) {
   mvit_gemm_args a = a0;
-  a.flags &= ~(0x2000 | 0x4000 | 0x8000);
+  a.flags &= ~(0x2000 | 0x4000 | 0x8000 | 0x10000);
   if (band_knob && ws_band_mode(a)) {
     a.flags |= 0x2000;
     return a.epi == MVIT_EPI_STORE ? launch_ws_one<MVIT_EPI_STORE, true>(a, s) : launch_ws_one<MVIT_EPI_SWIGLU, true>(a, s);
@@ -959,6 +1001,7 @@ int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_
   if (a.epi == MVIT_EPI_RESID && resid_single_knob && (long long)((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN) <= gemm_num_cus() &&
       a.K / ws::BK >= ws::RES_STEPS + 3 && !a.A2)
     a.flags |= 0x4000;
+  if (a.epi == MVIT_EPI_STORE && !pack_store_knob) a.flags |= 0x10000;   // (measurement: the f32-panel store epilogue)
   if (a.epi == MVIT_EPI_DSWIGLU && dsw_reg_knob) a.flags |= 0x8000;     // operand of the d(SwiGLU) epilogue through the producers' registers
   switch (a.epi) {
     case MVIT_EPI_STORE: return launch_ws_one<MVIT_EPI_STORE, false>(a, s);

@@ -16,11 +16,11 @@ run bench_unetr_train --generator unet_lora --no-cpu-baseline --steps 10 --warmu
 run bench_unetr_infer_b64 --generator unet_lora --mode infer --batch 64 --steps 10 --warmup 3
 MIPHEI_FORCE_DDP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 \
     > $O/bench_train_rccl_1rank.json 2> $O/bench_train_rccl_1rank.err              # the bucketed exchange on one rank
-rocprofv3 --kernel-trace --stats -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --comm-standin 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --comm-standin 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --comm-standin 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --comm-standin 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --comm-standin 0 > /dev/null 2>&1
 python3 tools/step_counters.py $O/trace $O/pmc_sq $O/pmc_fetch $O/pmc_write > $O/step_counters.txt 2> $O/step_counters.err
 db=$(ls $O/stats/*/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python3 tools/prof_summary.py $db 70 > $O/kernel_stats_train.txt
