@@ -8,6 +8,8 @@ namespace mvit_gemm {
 int gemm_num_cus() { return mvit_num_cus(); }
 bool ws_supported(const mvit_gemm_args& a);           // gemm_ws.hip: the wave-specialised 256x128 kernel (round 4)
 int launch_ws(const mvit_gemm_args& a, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob, int pack_store_knob);
+bool ws4_supported(const mvit_gemm_args& a);          // gemm_ws4.hip: the same pipeline with one 128x64 consumer wave per SIMD (plain bf16 stores)
+int launch_ws4(const mvit_gemm_args& a, hipStream_t s);
 }  // namespace mvit_gemm
 
 extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t stream) {
@@ -119,6 +121,14 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   MVIT_KNOB(ws_rsingle, "MVIT_GEMM_WS_RSINGLE", 1);   // 0: one-round residual GEMMs keep the consumer-side epilogue (measurement)
   MVIT_KNOB(ws_dswreg, "MVIT_GEMM_WS_DSWREG", 1);     // 0: the d(SwiGLU) operand as DMA'd pseudo tiles (two steps ahead) instead of the register prefetch
   MVIT_KNOB(ws_packst, "MVIT_GEMM_WS_PACKST", 1);     // 0: plain bf16 stores through the f32 panel (measurement)
+  // one-wave-per-SIMD consumers for the plain bf16 store problems: bit 0 = every such problem, bit 1 = only one-round launches
+  // (tiles <= CUs), bit 2 = only multi-round launches
+  MVIT_KNOB(ws4, "MVIT_GEMM_WS4", 0);
+  if (ws4 && takes_ws(a, v) && ws4_supported(a)) {
+    const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 128);
+    const bool one_round = tiles <= gemm_num_cus();
+    if ((ws4 & 1) || ((ws4 & 2) && one_round) || ((ws4 & 4) && !one_round)) return launch_ws4(a, s);
+  }
   if (takes_ws(a, v)) return launch_ws(a, s, ws_band, ws_rsingle, ws_dswreg, ws_packst);
 #ifdef MVIT_DEBUG_KNOBS
   if (v == id(256, 256, 2, 2)) return launch_dense<256, 256, 2, 2>(a, s);
