@@ -500,7 +500,7 @@ def pmc_traffic_all():
     return out
 
 
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic(kernel="gemm_kernel<256, 128, 4, 2, 0, 0>"):
@@ -511,10 +511,12 @@ def pmc_traffic(kernel="gemm_kernel<256, 128, 4, 2, 0, 0>"):
     for name in PMC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                k = json.load(f)["kernels"]
+                doc = json.load(f)
+            k = doc["kernels"]
             for kn, v in k.items():
                 if kernel in kn or kernel.rstrip(">") + "," in kn:
-                    return round(v["hbm_bytes_per_launch_corrected"]), f"profiles/{name} (static: committed rocprofv3 --pmc passes)"
+                    return round(v["hbm_bytes_per_launch_corrected"]), (f"profiles/{name} (static: committed rocprofv3 --pmc passes "
+                                                                        f"of the build at commit {doc.get('commit', 'unknown')})")
         except Exception:  # noqa: BLE001
             continue
     return None, None

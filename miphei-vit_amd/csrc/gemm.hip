@@ -121,14 +121,18 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   MVIT_KNOB(ws_rsingle, "MVIT_GEMM_WS_RSINGLE", 1);   // 0: one-round residual GEMMs keep the consumer-side epilogue (measurement)
   MVIT_KNOB(ws_dswreg, "MVIT_GEMM_WS_DSWREG", 1);     // 0: the d(SwiGLU) operand as DMA'd pseudo tiles (two steps ahead) instead of the register prefetch
   MVIT_KNOB(ws_packst, "MVIT_GEMM_WS_PACKST", 1);     // 0: plain bf16 stores through the f32 panel (measurement)
-  // one-wave-per-SIMD consumers for the plain bf16 store problems: bit 0 = every such problem, bit 1 = only one-round launches
-  // (tiles <= CUs), bit 2 = only multi-round launches
+#ifdef MVIT_DEBUG_KNOBS
+  // measurement library only (gemm_ws4.hip): one-wave-per-SIMD consumers for the plain bf16 store problems: bit 0 = every such
+  // problem, bit 1 = only one-round launches (tiles <= CUs), bit 2 = only multi-round launches.  Measured in round 5: proj 26.2 vs
+  // 24.2 us, dfc1 120.9 vs 116.7, qkv 72.9 vs 69.5; step 468.6 vs 474.3 tiles/s with every store problem on it (-1.2 %), -0.5 %
+  // with either half: two consumer waves per SIMD stay
   MVIT_KNOB(ws4, "MVIT_GEMM_WS4", 0);
   if (ws4 && takes_ws(a, v) && ws4_supported(a)) {
     const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 128);
     const bool one_round = tiles <= gemm_num_cus();
     if ((ws4 & 1) || ((ws4 & 2) && one_round) || ((ws4 & 4) && !one_round)) return launch_ws4(a, s);
   }
+#endif
   if (takes_ws(a, v)) return launch_ws(a, s, ws_band, ws_rsingle, ws_dswreg, ws_packst);
 #ifdef MVIT_DEBUG_KNOBS
   if (v == id(256, 256, 2, 2)) return launch_dense<256, 256, 2, 2>(a, s);
