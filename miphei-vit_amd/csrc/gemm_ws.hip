@@ -436,6 +436,22 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
             }
             r_cur = RES_PER_STEP;
           }
+#ifdef MVIT_WS_DSW_DUMMYVALU
+          // measurement build (results are garbage): the VALU work a producer-side factor computation would add to a plain ring step
+          // (16 operand pairs x (8 elements x ~11 VALU incl. 2 transcendental) spread over 14 steps ~= 100 VALU + 18 transcendental)
+          if constexpr (KC < 0 && SL < 0) {
+            f32x4 x = __builtin_bit_cast(f32x4, pre[0]);
+#pragma unroll
+            for (int it = 0; it < MVIT_WS_DSW_DUMMYVALU; ++it) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x[e] * -1.44f));
+                x[e] = x[e] * sg * (1.f + x[e] * (1.f - sg)) + sg;
+              }
+            }
+            pre[0] = __builtin_bit_cast(u32x4, x);
+          }
+#endif
           // in flight, oldest first: request of step g + 1 | operand loads of step g - 1 | request of step g + 2 | operand loads of step g
           if (req || SL >= 0) wait_allow(r_prev + pieces + r_cur);
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

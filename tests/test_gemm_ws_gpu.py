@@ -164,12 +164,15 @@ def test_ws_single_round_residual_on_the_producer_waves(M, N, K):
         assert torch.equal(out4, out3)
 
 
-@pytest.mark.parametrize("M,H,K", [(5264, 4096, 1536), (5121, 512, 64), (5375, 1024, 128), (40000, 256, 192), (1024, 128, 64)])
+@pytest.mark.parametrize("M,H,K", [(5264, 4096, 1536), (5121, 512, 64), (5375, 1024, 128), (40000, 256, 192), (1024, 128, 64),
+                                   (5121, 1024, 704), (70000, 256, 640), (5375, 4096, 576)])
 def test_ws_dswiglu_operand_on_pseudo_k_tiles(M, H, K):
     """d(SwiGLU) epilogue with the saved pre-activation DMA'd into the operand ring as pseudo K tiles (csrc/gemm_ws.hip, round 5):
     the benchmark's dfc2 shape (2.6 rounds of tiles), ragged last tile rows with 1 and 255 valid rows, many tiles per block with a
     single K tile each (the ring then carries more pseudo tiles than real ones), guard rows behind the output, a padded leading
-    dimension of the saved tensor, run-to-run identity."""
+    dimension of the saved tensor, run-to-run identity.  From 10 K tiles on the operand is prefetched into the producers' registers
+    and written into the ring by ds_write (K = 640 / 704: the smallest such loops, one and many tiles per block, ragged rows);
+    below that (K = 576 and less) the pseudo tiles are DMA'd."""
     import miphei_vit_amd.ops as ops
     assert _is_ws(M, H, K, epi=ops.EPI_DSWIGLU)
     g = torch.Generator(device="cuda").manual_seed(M + H + K)
