@@ -265,8 +265,15 @@ __global__ __launch_bounds__(CW_THREADS) void conv3x3_chunked_wgrad_kernel(const
   const int ntiles = p.B * tiles_y * tiles_x;
   const int nchunk = (p.Cin + CC_CK - 1) / CC_CK, nslice = (p.Cout + CC_NS - 1) / CC_NS;
   const int npair = nchunk * nslice;
-  const int pair = blockIdx.x % npair, group = blockIdx.x / npair;
-  const int slice = pair / nchunk, chunk = pair - slice * nchunk;
+  // Block -> (tile group, pair).  Round 5: the hardware places workgroup L on XCD L % 8, and the pairs that share operands should share
+  // an L2: each XCD gets a CONTIGUOUS run of the (group, chunk, slice) order with the slice running fastest, so the nslice blocks that read
+  // the same X chunk sit on one XCD, and that XCD streams each dY slice once for its ~npair / 8 / nslice chunks (before: pair = L % npair,
+  // i.e. the blocks of one chunk on different XCDs -- 512 MB of fabric traffic per launch of the 1728 -> 256 layer against ~65 MB of
+  // operands, profiles/r04_pmc_traffic.json).  Bijective for any block count (the XCD-contiguous renumbering of gemm_ws.hip's TileOrder).
+  const int nb = gridDim.x, L = blockIdx.x, xq = nb >> 3, xr = nb & 7, xcd = L & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (L >> 3);
+  const int group = wg / npair, pair = wg - group * npair;
+  const int chunk = pair / nslice, slice = pair - chunk * nslice;
   auto rsrc = [](const void* ptr) __attribute__((always_inline)) {
     const unsigned long long v = (unsigned long long)ptr;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));

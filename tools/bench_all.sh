@@ -34,13 +34,16 @@ python3 tools/bench_vs_blas.py > $O/gemm_vs_hipblaslt.txt 2>/dev/null
 python3 tools/bench_decoder_convs.py > $O/decoder_convs.txt 2>/dev/null
 python3 tools/bench_small.py > $O/small_kernels.txt 2>/dev/null
 python3 tools/bench_lora_wgrad.py > $O/lora_wgrad.txt 2>/dev/null
+# where a wave-specialised GEMM launch's time goes (timing build: make DEBUG_KNOBS=1 BUILD=build_tm LIB=../libmiphei_tm.so EXTRA=-DMVIT_WS_TIMING)
+[ -f miphei-vit_amd/libmiphei_tm.so ] && MIPHEI_LIB=miphei-vit_amd/libmiphei_tm.so python3 tools/ws_timing.py 2>/dev/null | grep -v amdgpu.ids > $O/ws_timing.txt
+python3 tools/gemm_power.py 2>/dev/null | grep -v amdgpu.ids > $O/gemm_power_8k.txt
 # run-to-run identity of the whole step (deterministic mode, 1000 repeats of forward + loss + backward on one input, bitwise) and of the
 # hipGraph-free inference forward at batch 64
 { MIPHEI_DETERMINISTIC=1 python3 tools/debug/step_soak.py 1000 16 256 myvitmatte train 2>/dev/null | tail -2
   MIPHEI_DETERMINISTIC=1 python3 tools/debug/step_soak.py 500 64 256 myvitmatte infer 2>/dev/null | tail -1; } > $O/step_soak.txt
 if [ "${COPY:-1}" = 1 ]; then
   for f in $O/bench_*.json $O/kernel_stats_train.txt $O/pmc_traffic.json $O/step_counters.txt $O/gemm_sq_counters.txt $O/gemm_epilogues.txt \
-           $O/gemm_vs_hipblaslt.txt $O/attn.txt $O/decoder_convs.txt $O/small_kernels.txt $O/lora_wgrad.txt $O/step_soak.txt; do
+           $O/gemm_vs_hipblaslt.txt $O/attn.txt $O/decoder_convs.txt $O/small_kernels.txt $O/lora_wgrad.txt $O/step_soak.txt $O/ws_timing.txt; do
     [ -s "$f" ] && cp $f profiles/${R}_$(basename $f)
   done
 fi
