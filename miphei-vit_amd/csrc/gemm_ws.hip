@@ -93,6 +93,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
 struct WsExtra {
   unsigned grid_magic;       // mvit_div_magic(gridDim.x)
   unsigned pg_magic;         // mvit_div_magic(GROUP_M * tiles_n), tiles_n = N / BN (band mode: same tiles_n)
+  // band mode: which blocks take the band items.  0xffffffff: block L takes item L (items spread evenly over the XCDs).  Otherwise 4 bits
+  // per XCD = its rank (0 = takes items first): block L on XCD L % 8 takes item rank * (blocks / 8) + L / 8, so the XCDs ranked last --
+  // the ones the host measured SLOWEST (tools/xcd_speed.py: the eight XCDs settle at clocks +-5 % apart) -- run no item behind their tiles
+  unsigned xcd_rank;
 };
 // x / g for the group heights 1 .. 4
 __device__ __forceinline__ int div_small(int x, int g) {
@@ -146,9 +150,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   constexpr int NPS = (EPI == MVIT_EPI_DSWIGLU && !BAND) ? NPSEUDO : 0;   // pseudo K tiles behind every unit's real ones
   const int nks = nk + NPS;                                                // ring steps per unit
   const int my_tiles = ((int)blockIdx.x < ord.ntiles) ? (int)mvit_fast_div((unsigned)(ord.ntiles - 1 - (int)blockIdx.x), gridDim.x, xp.grid_magic) + 1 : 0;
-  const bool has_item = BAND && (int)blockIdx.x < nq * ord.tiles_n;                // band item of this block: column bx / nq, quarter bx % nq
-  const int item_col = div_small((int)blockIdx.x, nq > 0 ? nq : 1);                // (nq <= 4: the band is lower than a tile)
-  const int item_m = rows_full + ((int)blockIdx.x - item_col * (nq > 0 ? nq : 1)) * 64, item_n = item_col * BN;
+  int item_id = (int)blockIdx.x;
+  if (BAND && xp.xcd_rank != 0xffffffffu && (gridDim.x & 7) == 0)
+    item_id = (int)((xp.xcd_rank >> (4 * (blockIdx.x & 7))) & 15u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const bool has_item = BAND && item_id < nq * ord.tiles_n;                        // band item of this block: column id / nq, quarter id % nq
+  const int item_col = div_small(item_id, nq > 0 ? nq : 1);                        // (nq <= 4: the band is lower than a tile)
+  const int item_m = rows_full + (item_id - item_col * (nq > 0 ? nq : 1)) * 64, item_n = item_col * BN;
   const int G = (my_tiles + (has_item ? 1 : 0)) * nks;  // ring steps this block walks (global step index g)
 #ifdef MVIT_WS_TIMING
   long long* prof = p.stats ? (long long*)p.stats + (size_t)blockIdx.x * 16 + (wave >= NCW ? 8 : 0) : nullptr;
@@ -978,6 +985,34 @@ bool ws_supported(const mvit_gemm_args& a) {
   return true;
 }
 
+// per-device XCD ranking for the band items (mvit_set_xcd_rank; 0xffffffff = not set: items spread evenly)
+static std::atomic<unsigned> g_xcd_rank[MVIT_MAX_DEVICES];
+static std::atomic<bool> g_xcd_rank_init{false};
+static unsigned xcd_rank_of_device() {
+  if (!g_xcd_rank_init.load(std::memory_order_acquire)) return 0xffffffffu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return 0xffffffffu;
+  const unsigned v = g_xcd_rank[dev].load(std::memory_order_relaxed);
+  return v ? v : 0xffffffffu;       // (0 = never set for this device; a real ranking is a permutation of 0 .. 7 and never packs to 0)
+}
+int set_xcd_rank(const int* rank8) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return MVIT_EINVAL;
+  unsigned v = 0, seen = 0;
+  if (rank8) {
+    for (int x = 0; x < 8; ++x) {
+      if (rank8[x] < 0 || rank8[x] > 7) return MVIT_EINVAL;
+      seen |= 1u << rank8[x];
+      v |= (unsigned)rank8[x] << (4 * x);
+    }
+    if (seen != 0xffu) return MVIT_EINVAL;          // a permutation of 0 .. 7
+  }
+  for (int d = 0; d < MVIT_MAX_DEVICES && !g_xcd_rank_init.load(std::memory_order_relaxed); ++d) g_xcd_rank[d].store(0u, std::memory_order_relaxed);
+  g_xcd_rank[dev].store(rank8 ? v : 0u, std::memory_order_relaxed);
+  g_xcd_rank_init.store(true, std::memory_order_release);
+  return MVIT_OK;
+}
+
 template <int EPI, bool BAND>
 static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN);
@@ -990,6 +1025,7 @@ static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   ws::WsExtra xp;
   xp.grid_magic = mvit_div_magic((unsigned)gx);
   xp.pg_magic = mvit_div_magic((unsigned)(MVIT_WS_GROUP_M * (a.N / ws::BN)));
+  xp.xcd_rank = xcd_rank_of_device();
   hipLaunchKernelGGL(kern, dim3(gx), dim3(64 * (ws::NCW + ws::NPW)), lds, s, a, xp);
   return MVIT_LAUNCH_CHECK();
 }
