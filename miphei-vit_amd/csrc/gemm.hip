@@ -125,7 +125,7 @@ static int dispatch(const mvit_gemm_args& a, hipStream_t s) {
   // (Measured and dropped in round 4: a ragged-M split -- rows [0, 5120) of fc1 as exactly five rounds of 256-row tiles on this kernel,
   // the remaining 144 rows as a second launch on the 128-row tiles -- 137.8 vs 133-135 us: the small launch costs what the sixth,
   // three-quarters-empty round costs.)
-  MVIT_KNOB(ws_band, "MVIT_GEMM_WS_BAND", 1);     // 0: the ragged last tile row always as whole 256-row tiles (measurement)
+  MVIT_KNOB(ws_band, "MVIT_GEMM_WS_BAND", 1);     // 0: the ragged last tile row always as whole 256-row tiles; 2: band items spread evenly over the XCDs (measurement)
   MVIT_KNOB(ws_rsingle, "MVIT_GEMM_WS_RSINGLE", 1);   // 0: one-round residual GEMMs keep the consumer-side epilogue (measurement)
   MVIT_KNOB(ws_dswreg, "MVIT_GEMM_WS_DSWREG", 1);     // 0: the d(SwiGLU) operand as DMA'd pseudo tiles (two steps ahead) instead of the register prefetch
   MVIT_KNOB(ws_packst, "MVIT_GEMM_WS_PACKST", 1);     // 0: plain bf16 stores through the f32 panel (measurement)

@@ -966,7 +966,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 
 // problems the wave-specialised kernel takes (everything else stays on gemm_kernel.hpp)
 bool ws_supported(const mvit_gemm_args& a) {
-  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000 | 0x4000 | 0x8000 | 0x10000))) return false;
+  if (a.amode != MVIT_A_DENSE || a.ksplit > 1 || (a.flags & (MVIT_ATOMIC | 0x400 | 0x800 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000))) return false;
   if (a.epi != MVIT_EPI_STORE && a.epi != MVIT_EPI_SWIGLU && a.epi != MVIT_EPI_RESID && a.epi != MVIT_EPI_DSWIGLU) return false;
   if (a.M < 1024 || (a.N % 128) || (a.K % 64) || a.K < 64) return false;
   if (a.A2 && (a.K2 > 64 || a.K2 <= 0)) return false;
@@ -985,15 +985,21 @@ bool ws_supported(const mvit_gemm_args& a) {
   return true;
 }
 
-// per-device XCD ranking for the band items (mvit_set_xcd_rank; 0xffffffff = not set: items spread evenly)
+// Per-device XCD ranking for the band items.  Default = the identity ranking: item rank * 32 + L / 8, i.e. the items in XCD-CONTIGUOUS
+// order -- the nq items of one tile column (same B panel) on one XCD, two XCDs without items.  Measured (tools/xcd_speed.py, fc1 + SwiGLU
+// at batch 16): 122.4-128.8 us with the items spread evenly (item L on block L), 116.8-118.2 with ANY contiguous placement; ranking the
+// XCDs by measured speed (mvit_xcd_probe + mvit_set_xcd_rank, miphei_vit_amd/xcd.py, opt-in) added nothing on a box whose XCDs were
+// +-2 % apart.
 static std::atomic<unsigned> g_xcd_rank[MVIT_MAX_DEVICES];
 static std::atomic<bool> g_xcd_rank_init{false};
-static unsigned xcd_rank_of_device() {
-  if (!g_xcd_rank_init.load(std::memory_order_acquire)) return 0xffffffffu;
+static unsigned xcd_rank_of_device(int even_knob) {
+  constexpr unsigned IDENTITY = 0x76543210u;
+  if (even_knob) return 0xffffffffu;                 // (measurement: item L on block L)
+  if (!g_xcd_rank_init.load(std::memory_order_acquire)) return IDENTITY;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return 0xffffffffu;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return IDENTITY;
   const unsigned v = g_xcd_rank[dev].load(std::memory_order_relaxed);
-  return v ? v : 0xffffffffu;       // (0 = never set for this device; a real ranking is a permutation of 0 .. 7 and never packs to 0)
+  return v ? v : IDENTITY;          // (0 = never set for this device; a ranking is a permutation of 0 .. 7 and never packs to 0)
 }
 int set_xcd_rank(const int* rank8) {
   int dev = 0;
@@ -1025,7 +1031,7 @@ static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   ws::WsExtra xp;
   xp.grid_magic = mvit_div_magic((unsigned)gx);
   xp.pg_magic = mvit_div_magic((unsigned)(MVIT_WS_GROUP_M * (a.N / ws::BN)));
-  xp.xcd_rank = xcd_rank_of_device();
+  xp.xcd_rank = xcd_rank_of_device(BAND ? (a.flags >> 17) & 1 : 0);
   hipLaunchKernelGGL(kern, dim3(gx), dim3(64 * (ws::NCW + ws::NPW)), lds, s, a, xp);
   return MVIT_LAUNCH_CHECK();
 }
@@ -1044,16 +1050,17 @@ bool ws_band_mode(const mvit_gemm_args& a) {
 
 int launch_ws(const mvit_gemm_args& a0, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob, int pack_store_knob) {
   mvit_gemm_args a = a0;
-  a.flags &= ~(0x2000 | 0x4000 | 0x8000 | 0x10000);
+  a.flags &= ~(0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000);
+  if (a.epi == MVIT_EPI_STORE && !pack_store_knob) a.flags |= 0x10000;   // (measurement: the f32-panel store epilogue)
   if (band_knob && ws_band_mode(a)) {
     a.flags |= 0x2000;
+    if (band_knob == 2) a.flags |= 0x20000;                              // (measurement: band items spread evenly over the XCDs)
     return a.epi == MVIT_EPI_STORE ? launch_ws_one<MVIT_EPI_STORE, true>(a, s) : launch_ws_one<MVIT_EPI_SWIGLU, true>(a, s);
   }
   // single-round residual epilogue on the producer waves (every block owns one tile, enough K steps to carry the residual requests)
   if (a.epi == MVIT_EPI_RESID && resid_single_knob && (long long)((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN) <= gemm_num_cus() &&
       a.K / ws::BK >= ws::RES_STEPS + 3 && !a.A2)
     a.flags |= 0x4000;
-  if (a.epi == MVIT_EPI_STORE && !pack_store_knob) a.flags |= 0x10000;   // (measurement: the f32-panel store epilogue)
   if (a.epi == MVIT_EPI_DSWIGLU && dsw_reg_knob) a.flags |= 0x8000;     // operand of the d(SwiGLU) epilogue through the producers' registers
   switch (a.epi) {
     case MVIT_EPI_STORE: return launch_ws_one<MVIT_EPI_STORE, false>(a, s);

@@ -1,7 +1,9 @@
 """Per-XCD speed ranking (round 5).  Under a dense bf16 MFMA load the eight XCDs of an MI355X settle at clocks several per cent apart
 -- stable over a run, different from box to box (tools/ws_timing.py, docs/rounds/round5.md) -- and a statically partitioned launch ends
 with its slowest XCD.  Where a launch has slack to place (the band items of a ragged wave-specialised GEMM: 192 items for 256 CUs at
-batch 16), the library places it by this ranking.  Measured once per device and process (~2 ms), off with MIPHEI_XCD_RANK=0."""
+batch 16), the library can place it by this ranking.  OPT-IN (MIPHEI_XCD_RANK=1, then measured once per device and process, ~2 ms):
+on the boxes of round 5 the XCDs were only +-2 % apart under this probe and the ranking was within its own noise; what pays is the
+XCD-contiguous placement the library uses by default (csrc/gemm_ws.hip: fc1 + SwiGLU 122.5 -> 117.5 us)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -40,7 +42,7 @@ def measure(device=None, iters=2000, repeats=5):
 
 def apply(device=None, force=False):
     """measure and install the ranking for the device (once per process); returns the ranking or None when switched off"""
-    if os.environ.get("MIPHEI_XCD_RANK", "1") == "0":
+    if os.environ.get("MIPHEI_XCD_RANK", "0") != "1" and not force:
         return None
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = dev.index
