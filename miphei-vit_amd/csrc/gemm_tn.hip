@@ -56,10 +56,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wave_i = wave / WJ, wave_j = wave % WJ;
   const int half = lane >> 5, l31 = lane & 31;
-  const int i0 = blockIdx.x * IT, j0 = blockIdx.y * JT;
+  // Block coordinates.  Round 5: the hardware places the workgroup of linear index L (x fastest, then y, then z) on XCD L % 8, and the
+  // gx * gy blocks of one (product, m slice) read the SAME rows of both operands -- as hardware coordinates they sat on gx * gy different
+  // XCDs (the conv weight gradients: 164 MB of fabric traffic per launch against 38 MB of operands, profiles/r04_pmc_traffic.json).
+  // The XCD-contiguous renumbering of gemm_ws.hip's TileOrder puts them on one XCD (x fastest inside a slice).
+  const int gx = gridDim.x, gy = gridDim.y, gxy = gx * gy, nblk = gxy * (int)gridDim.z;
+  const int Lb = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+  const int xq_ = nblk >> 3, xr_ = nblk & 7, xcd_ = Lb & 7;
+  const int wg_ = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + (Lb >> 3);
+  const int bz = wg_ / gxy, rem_ = wg_ - bz * gxy, by = rem_ / gx, bx = rem_ - by * gx;
+  const int i0 = bx * IT, j0 = by * JT;
   const long long nsteps = ((long long)p.M + 63) / 64;
   const int nb = p.batch > 1 ? p.batch : 1;
-  const int nz = gridDim.z / nb, bi = blockIdx.z / nz, zi = blockIdx.z - bi * nz;   // (product, slice of m)
+  const int nz = gridDim.z / nb, bi = bz / nz, zi = bz - bi * nz;   // (product, slice of m)
   const long long per = (nsteps + nz - 1) / nz;
   const long long s_begin = zi * per, s_end = min(nsteps, s_begin + per);
   if (s_begin >= s_end) return;
