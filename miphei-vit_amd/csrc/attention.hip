@@ -379,6 +379,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
                                                           const bf16_t* __restrict__ ores,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                           float* __restrict__ Dv, bf16_t* __restrict__ dqkv, AttnDims dm) {
+#ifdef MVIT_ATTN_TIMING
+  long long tsum[5] = {0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+  const long long tstart = tlast;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING_Q][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -391,6 +395,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
   const bf16_t* vb = kb + (size_t)dm.H * Dh;
   const bf16_t* dob = dO + (size_t)b * N * ors + (size_t)h * Dh;
   const int q = bxy.x * 128 + wave * 32 + l31;
+
+  // first K / V tile on its way before the fragment loads below (their use in the D sum would otherwise put one whole memory
+  // round trip in front of the DMA's)
+  const int ntiles = (N + KVB - 1) / KVB;
+  const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
+  const TileOff to = tile_offsets(Dh, (unsigned)rs, tid);
+  auto issue = [&](int t, char* dst) {
+    dma_tile(rK, dst, to, t * KVB, N, (unsigned)rs, tid);
+    dma_tile(rV, dst + TILE_BYTES, to, t * KVB, N, (unsigned)rs, tid);
+  };
+  issue(0, smem);
 
   bf16x8 qf[4], dof[4];
   float dsum = 0.f;
@@ -427,22 +442,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
-  const int ntiles = (N + KVB - 1) / KVB;
-  const __amdgpu_buffer_rsrc_t rK = make_rsrc(kb), rV = make_rsrc(vb);
-  const TileOff to = tile_offsets(Dh, (unsigned)rs, tid);
-  auto issue = [&](int t, char* dst) {
-    dma_tile(rK, dst, to, t * KVB, N, (unsigned)rs, tid);
-    dma_tile(rV, dst + TILE_BYTES, to, t * KVB, N, (unsigned)rs, tid);
-  };
-  issue(0, smem);
   auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     constexpr bool RAGGED = decltype(ragged_tag)::value;
+    ATT_STAMP(t == 0 ? 0 : 2)
     // lgkmcnt(0) too: s_barrier does not wait for LDS reads in flight, and hipcc sinks the MFMAs that consume the previous tile's last
     // fragment reads below this barrier (they are not memory operations) -- the reads then cross it unfinished while the other waves
     // issue the DMA that refills their slot (round 4: one 32-query slab in ~1e4 launches came back with a few stale K / V^T rows)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave is done with tile t-1 (the other slot)
+    ATT_STAMP(1)
+#ifdef MVIT_ATTN_TIMING
+    tsum[4] += 1;
+#endif
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
     const char* Ks = smem + SLOT * 2 * TILE_BYTES;
     const char* Vs = Ks + TILE_BYTES;
@@ -513,6 +525,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     run(std::false_type{});
   else
     run(std::true_type{});
+  ATT_STAMP(2)
   {
     uint2 wq[2][4];
 #pragma unroll
@@ -524,13 +537,29 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
       }
     store_row_groups(dqkv + ((size_t)b * N + (q < N ? q : 0)) * rs + (size_t)h * Dh, Dh, half, wq, q < N);
   }
+#ifdef MVIT_ATTN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_STAMP(3)
+  if (lane == 0) {
+    long long* prof = (long long*)(Dv + (size_t)dm.B * dm.H * N) + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int k = 0; k < 5; ++k) prof[k] = tsum[k];
+    prof[5] = (long long)__builtin_readcyclecounter();
+    prof[6] = tstart;
+    prof[7] = __builtin_amdgcn_s_getreg((8 << 11) | (0 << 6) | 20) /* XCC_ID */;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ backward, dK / dV (key-stationary, S form)
 //   S = Q K^T, P = exp(S*scale - L_q), dP = dO V^T, dS = P*(dP - D_q)*scale, dV^T += dO^T P, dK^T += Q^T dS
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
-                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                           const float* __restrict__ lse, const float* __restrict__ Dv_c,
                                                            bf16_t* __restrict__ dqkv, AttnDims dm) {
+  float* Dv = const_cast<float*>(Dv_c);   // (the timing build writes its stamps behind the D values)
+#ifdef MVIT_ATTN_TIMING
+  long long tsum[5] = {0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+  const long long tstart = tlast;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][Q|dO] + L[Npad] + D[Npad] (f32)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -581,8 +610,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   auto step = [&](int t, auto slot_tag, auto ragged_tag, auto live_tag) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     constexpr bool RAGGED = decltype(ragged_tag)::value;
+    ATT_STAMP(t == 0 ? 0 : 2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (lgkmcnt: see the forward kernel's step)
     __builtin_amdgcn_s_barrier();
+    ATT_STAMP(1)
+#ifdef MVIT_ATTN_TIMING
+    tsum[4] += 1;
+#endif
     if (t + 1 < ntiles) issue(t + 1, smem + (SLOT ^ 1) * 2 * TILE_BYTES);
     const char* Qs = smem + SLOT * 2 * TILE_BYTES;
     const char* Ds = Qs + TILE_BYTES;
@@ -661,6 +695,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     run(std::false_type{});
   else
     run(std::true_type{});
+  ATT_STAMP(2)
   {
     uint2 wk[2][4], wv[2][4];
 #pragma unroll
@@ -676,6 +711,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     store_row_groups(krow, Dh, half, wk, key < N);
     store_row_groups(krow + (size_t)dm.H * Dh, Dh, half, wv, key < N);
   }
+#ifdef MVIT_ATTN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_STAMP(3)
+  if (lane == 0) {
+    long long* prof = (long long*)(Dv + (size_t)dm.B * dm.H * N) + ((size_t)(gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    for (int k = 0; k < 5; ++k) prof[k] = tsum[k];
+    prof[5] = (long long)__builtin_readcyclecounter();
+    prof[6] = tstart;
+    prof[7] = __builtin_amdgcn_s_getreg((8 << 11) | (0 << 6) | 20) /* XCC_ID */;
+  }
+#endif
 }
 
 }  // namespace
