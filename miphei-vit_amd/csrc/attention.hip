@@ -37,7 +37,14 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr int KVB = 64;          // keys per LDS tile
 constexpr int TILE_BYTES = KVB * 128;  // 64 rows x 64 bf16
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// XOR swizzle of a tile row's eight 16-byte chunks.  The key is a bit permutation of (row >> 1) & 7 -- row bit 1 on chunk bit 2, row
+// bits 2, 3 on chunk bits 0, 1 -- so that BOTH read patterns are conflict-free: the b128 fragment reads (32 consecutive rows, one
+// chunk: any bijection of the three bits does) and the transposing b64 reads, whose 32-lane group covers 4 consecutive rows x 64
+// bytes: rows r and r + 2 lie 256 bytes = one bank sweep apart and must take different 64-byte halves, i.e. row bit 1 has to
+// reach chunk bit 2.  (Through round 4 the key was (row >> 1) & 7 itself: every transposing read 2-way conflicted, 25-32 % of the
+// LDS cycles of the three kernels -- SQ_LDS_BANK_CONFLICT in profiles/r02_attn_counters.txt; model: tools/debug/attn_lds_banks.py.)
+__device__ __forceinline__ int swz_key(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ swz_key(row)) << 4); }
 
 // 4 consecutive rows x this lane's column, from a row-major [rows][64] bf16 tile (hardware transpose read):
 // a 16-lane group addresses a 4x16 block (lane i: row i>>2, cols 4*(i&3)..+3) and lane i receives column i.
@@ -70,7 +77,7 @@ __device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned ma
 
 // DMA one 64-row x 64-col bf16 tile (rows row0.. of a matrix with row stride `rs` elements) straight into LDS
 // (buffer_load ... lds, 16 B per lane): lane l of a wave fills row l>>3, 16-byte slot l&7 of 8 consecutive rows; the
-// XOR swizzle is applied to the SOURCE chunk (slot s of row r holds chunk s ^ ((r>>1)&7)); rows >= nvalid and
+// XOR swizzle is applied to the SOURCE chunk (slot s of row r holds chunk s ^ swz_key(r)); rows >= nvalid and
 // columns >= Dh come back as zeros through an out-of-range offset.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const bf16_t* ptr) {
   const unsigned long long v = (unsigned long long)ptr;
@@ -86,7 +93,7 @@ __device__ __forceinline__ TileOff tile_offsets(int Dh, unsigned rs, int tid) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = 8 * wave_u + 32 * j + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int c = (lane & 7) ^ swz_key(row);
     o.full[j] = c * 8 < Dh ? ((unsigned)row * rs + (unsigned)c * 8u) * 2u : 0x80000000u;
   }
   return o;
