@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--graph", type=int, default=1, help="infer mode: replay a hipGraph-captured forward")
     ap.add_argument("--probe", type=int, default=1, help="0: no HIP-event probe of the dominant kernel (no `roofline` object)")
     ap.add_argument("--chunked-conv", type=int, default=1, help="0: wide fusion blocks on the implicit GEMM (A/B of csrc/conv_chunked.hip)")
+    ap.add_argument("--bn-fold", type=int, default=1, help="0: eval-mode BatchNorm applied by its own kernels instead of folded into the ConvStream (A/B)")
     ap.add_argument("--attn-residual", type=int, default=1, help="0: attention backward forms D from the bf16 output alone (A/B)")
     ap.add_argument("--lora-group", type=int, default=0, help="ViT blocks per batched LoRA weight-gradient launch (0 = engine default)")
     ap.add_argument("--lora-buckets", type=int, default=4, help="sub-buckets of the LoRA gradient all-reduce (N > 1)")
@@ -269,6 +270,7 @@ def main(argv=None):
     eng = model._engine
     if hasattr(eng, "use_chunked_conv"):
         eng.use_chunked_conv, eng.attn_residual = bool(a.chunked_conv), bool(a.attn_residual)
+        eng.bn_fold = bool(a.bn_fold)
     if a.lora_group > 0:
         (eng._encoder_engine() if hasattr(eng, "_encoder_engine") else eng).lora_group = a.lora_group
     if unet and not hasattr(eng, "capture_inference"):

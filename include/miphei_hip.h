@@ -37,7 +37,14 @@ enum mvit_epilogue {
   MVIT_EPI_DSWIGLU = 6,  /* C[m, packed a|b] = d(silu(a)*b) * acc, aux = saved [a|b]         */
   MVIT_EPI_DGELU = 7     /* C = acc * gelu'(aux)                                             */
 };
-enum mvit_gemm_flags { MVIT_OUT_F32 = 1, MVIT_ATOMIC = 2 /* f32 atomicAdd (split-K) */, MVIT_ACCUM_BF16 = 4 /* C(bf16) += */ };
+enum mvit_gemm_flags {
+  MVIT_OUT_F32 = 1,
+  MVIT_ATOMIC = 2,      /* f32 atomicAdd (split-K) */
+  MVIT_ACCUM_BF16 = 4,  /* C(bf16) += */
+  MVIT_RELU = 8         /* C = max(acc + bias, 0): convolution with an eval-mode BatchNorm folded into its weights (scale) and bias
+                         * (shift) and the ReLU behind it (Basic_Conv3x3, src/generators/mipheivit.py:20-41, in model.eval());
+                         * EPI_STORE with a CONV3 operand and bf16 output only */
+};
 enum mvit_amode { MVIT_A_DENSE = 0, MVIT_A_CONV3 = 1, MVIT_A_CONV3_T = 2, MVIT_A_PATCH = 3 };
 
 /*

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmiphei_hip.so")
 
 # enum mvit_epilogue
 EPI_STORE, EPI_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_STATS, EPI_DSWIGLU, EPI_DGELU = range(8)
-OUT_F32, ATOMIC, ACCUM_BF16 = 1, 2, 4
+OUT_F32, ATOMIC, ACCUM_BF16, RELU = 1, 2, 4, 8
 A_DENSE, A_CONV3, A_CONV3_T, A_PATCH = 0, 1, 2, 3
 
 vp, ci, cf, cd, ll = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong

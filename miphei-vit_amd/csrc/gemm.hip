@@ -30,6 +30,8 @@ extern "C" MVIT_API int mvit_gemm_bf16(const mvit_gemm_args* args, mvit_stream_t
   }
   if (a.A2 && ((a.K2 & 7) || (a.lda2 & 7) || (a.ldb2 & 7) || !a.B2)) return MVIT_EINVAL;
   if (a.ksplit > 1 && !(a.flags & MVIT_ATOMIC)) return MVIT_EINVAL;
+  if ((a.flags & MVIT_RELU) && (a.amode != MVIT_A_CONV3 || a.epi != MVIT_EPI_STORE || (a.flags & (MVIT_OUT_F32 | MVIT_ATOMIC | MVIT_ACCUM_BF16))))
+    return MVIT_EINVAL;
   if (a.epi == MVIT_EPI_STATS && (!a.stats || a.nslots <= 0)) return MVIT_EINVAL;
   if ((a.epi == MVIT_EPI_DSWIGLU || a.epi == MVIT_EPI_DGELU) && !a.aux) return MVIT_EINVAL;
   if (a.epi == MVIT_EPI_PATCH && (!a.pos || a.patch_P <= 0)) return MVIT_EINVAL;

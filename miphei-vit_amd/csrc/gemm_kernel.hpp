@@ -962,6 +962,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
               for (int e = 0; e < V; ++e) v[e] += bias[e];
               if constexpr (EPI == MVIT_EPI_STORE) {
                 const size_t o = (size_t)row * p.ldc + col;
+                if constexpr (AMODE == MVIT_A_CONV3) {   // (folded BatchNorm + ReLU of the eval-mode ConvStream; the dispatcher admits the flag here only)
+                  if (p.flags & MVIT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[e] = fmaxf(v[e], 0.f);
+                  }
+                }
                 if (atomic) {
                   for (int e = 0; e < nv; ++e) atomicAdd(Cf + o + e, v[e]);
                 } else if (out_f32) {

@@ -24,7 +24,7 @@ import torch
 
 from . import ops
 from .ops import (A_CONV3, A_CONV3_T, A_PATCH, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,
-                  EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
+                  EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32, RELU)
 from .resample import taps
 
 NSLOTS = ops.STAT_SLOTS          # statistic slots per BatchNorm layer (32; 256 = one per writer block with MIPHEI_DETERMINISTIC=1)
@@ -60,6 +60,9 @@ class HipEngine:
         #                              +0.3 % on the step)
         self.use_chunked_conv = True  # fusion blocks 0-2 on the chunked direct convolution (False: implicit GEMM, for A/B runs)
         self.attn_residual = True     # keep the bf16 rounding residual of the attention output for the backward's D term (A/B switch)
+        self.bn_fold = True           # eval mode: BatchNorm of the ConvStream folded into its convolutions (_bn_fold; A/B switch)
+        self._stats_gen = 0           # train-mode forwards so far: the kernels update the running statistics through raw pointers,
+        #                               which tensor._version does not see (key of the eval-mode fold)
         self.invalidate()
 
     # ------------------------------------------------------------------ state management
@@ -73,6 +76,7 @@ class HipEngine:
         self._flat = None
         self._ws = {}
         self._pack_key = None
+        self._fold_key = None
         self._saved = None
 
     @property
@@ -603,6 +607,37 @@ class HipEngine:
         ops.bn_finalize(w.stats_f[i], pk.bn[i].w, pk.bn[i].b, rm, rv, bp.scale, bp.shift,
                         bp.mean, bp.rstd, pk.bn[i].w.numel(), NSLOTS, count, BN_EPS, BN_MOM, bn_train)
 
+    def _bn_fold(self, pk, convs):
+        """Eval-mode BatchNorm as constants (SURVEY.md section 8f row 1 "BN fold", section 8d config 5): with running statistics
+        y = scale * conv(x) + shift, scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale
+        (nn.BatchNorm2d.eval() inside Basic_Conv3x3 / Fusion_Block, /root/reference/src/generators/mipheivit.py:20-41, 76-93).
+        ConvStream: scale goes into the packed convolution weights and shift + ReLU into the GEMM epilogue (bias, MVIT_RELU), which
+        writes the concat slice directly -- no pre-activation buffer, no bn_finalize / bn_relu_apply launches.  Fusion blocks:
+        scale / shift are computed here once instead of by one bn_finalize launch per layer and forward (their consumers -- the
+        up-sampling gather, the last block's apply pass -- take them as before).  Cached on the parameter and buffer versions."""
+        bns = [cv.bn for cv in convs]
+        key = (self._pack_key, self._stats_gen, tuple((b.running_mean._version, b.running_var._version, b.running_mean.data_ptr()) for b in bns))
+        if self._fold_key == key:
+            return self._fold
+        dev = self._require_gpu()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
+        fold = NS(wk=[], scale=[], shift=[])
+        packs = []
+        for i, cv in enumerate(convs):
+            bn = cv.bn
+            scale = f32(bn.weight) * torch.rsqrt(f32(bn.running_var) + BN_EPS)
+            shift = f32(bn.bias) - f32(bn.running_mean) * scale
+            fold.scale.append(scale.contiguous())
+            fold.shift.append(shift.contiguous())
+            if i < 3:
+                wf = (f32(cv.conv.weight) * scale[:, None, None, None]).contiguous()
+                wk = torch.empty_like(pk.wk[i])
+                packs.append((wf, wk, None, 0))
+                fold.wk.append(wk)
+        ops.pack_conv3x3_weights_multi(packs)
+        self._fold_key, self._fold = key, fold
+        return fold
+
     def _decoder_fwd(self, w, x, bn_train, pk, convs):
         c = self._config()
         B, D = w.B, c.D
@@ -612,6 +647,7 @@ class HipEngine:
         ty = taps(mode, c.grid, G, dev)
         ops.resample2d(w.tok[c.prefix:], w.feat, ty, ty, B=B, h=c.grid, w=c.grid, H=G, W=G, C=D, ld_src=D, ld_dst=D,
                        src_bstride=c.ntok * D, dst_bstride=G * G * D)
+        fold = self._bn_fold(pk, convs) if (not bn_train and self.bn_fold) else None
         im8 = w.img8_cur          # written (or adopted from the input stage) by _encoder_fwd
         # (the image slice of the last concat buffer is copied from img8 by the up-sampling kernel that fills the rest of it)
         # ConvStream: conv3x3 s2 -> BN -> ReLU, written into the skip slice of the matching concat buffer
@@ -622,6 +658,10 @@ class HipEngine:
             d, r_out = dst[i]
             Mo = B * r_out * r_out
             cout = CONV_CH[i + 1]
+            if fold is not None:
+                ops.gemm(a, fold.wk[i], d, M=Mo, N=cout, ldc=d.shape[-1], amode=A_CONV3, conv=(r_in, r_in, cin, ld, r_out, r_out, 2),
+                         bias=fold.shift[i], flags=RELU)
+                continue
             if bn_train:
                 ops.gemm(a, pk.wk[i], w.pre_c[i], M=Mo, amode=A_CONV3, conv=(r_in, r_in, cin, ld, r_out, r_out, 2),
                          epi=EPI_STATS, stats=w.stats_f[i], nslots=NSLOTS)
@@ -651,16 +691,18 @@ class HipEngine:
                          stats=w.stats_f[i], nslots=NSLOTS)
             else:
                 ops.gemm(cat, pk.wk[i], w.pre_f[j], M=Mo, amode=A_CONV3, conv=(r, r, cp, cp, r, r, 1))
-            self._bn(w, i, pk, convs[i], Mo, bn_train)
+            if fold is None:
+                self._bn(w, i, pk, convs[i], Mo, bn_train)
+            bscale, bshift = (w.bnp[i].scale, w.bnp[i].shift) if fold is None else (fold.scale[i], fold.shift[i])
             if j < 3:
                 nxt = w.cat[j + 1]
                 off = 0 if j == 2 else CONV_CH[2 - j]
                 ops.upsample2x_bilinear(w.pre_f[j], nxt.view(-1)[off:], B=B, h=r, w=r, C=FUS_OUT[j], ld_src=FUS_OUT[j],
                                         ld_dst=nxt.shape[-1], src_bstride=r * r * FUS_OUT[j],
-                                        dst_bstride=4 * r * r * nxt.shape[-1], scale=w.bnp[i].scale, shift=w.bnp[i].shift,
+                                        dst_bstride=4 * r * r * nxt.shape[-1], scale=bscale, shift=bshift,
                                         extra8=im8 if j == 2 else None)
             else:
-                ops.bn_relu_apply(w.pre_f[3], w.bnp[i].scale, w.bnp[i].shift, w.F3, Mo, 32, 32, 32)
+                ops.bn_relu_apply(w.pre_f[3], bscale, bshift, w.F3, Mo, 32, 32, 32)
         # heads
         Mp = B * S * S
         fl = self._flat
@@ -705,6 +747,7 @@ class HipEngine:
         out = self._decoder_fwd(w, x, bn_train, pk, convs)
         if bn_train:
             self._flat.nbt.add_(1)
+            self._stats_gen += 1
         if train:
             self._saved = NS(w=w, pk=pk, x=x, convs=convs, bn_train=bn_train)
         return out if in_dtype == torch.float32 else out.to(in_dtype)

@@ -8,7 +8,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (A_CONV3, A_CONV3_T, A_DENSE, A_PATCH, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,  # noqa: F401
-                   EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32)
+                   EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32, RELU)
 
 
 # MIPHEI_DETERMINISTIC=1 (read at import): run-to-run identical results.  Every reduction that normally meets in floating-point

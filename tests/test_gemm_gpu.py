@@ -193,6 +193,32 @@ def test_conv3x3_fwd_stats_and_dgrad(B, H, W, C, Cout, stride):
     assert _rel(dx, xg.grad.permute(0, 2, 3, 1).reshape(-1, C)) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,C,Cout,ldc", [(2, 64, 64, 8, 48, 176), (1, 32, 32, 48, 96, 352), (2, 16, 16, 96, 192, 192)])
+def test_conv3x3_bias_relu_into_a_wider_buffer(B, H, W, C, Cout, ldc):
+    """MVIT_RELU: the eval-mode ConvStream convolution with BatchNorm folded in (weights scaled, shift as bias) writes max(conv + bias, 0)
+    straight into its slice of a concat buffer (row stride ldc > Cout); the other columns stay untouched.  The flag is refused anywhere else."""
+    ops = _ops()
+    x = _rand(B, H, W, C, seed=1).bfloat16()
+    w = _rand(Cout, C, 3, 3, seed=2, scale=0.05)
+    bias = _rand(Cout, seed=3, scale=0.3)
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    M = B * OH * OW
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).bfloat16().contiguous()
+    y = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, wk, y, M=M, N=Cout, ldc=ldc, amode=ops.A_CONV3, conv=(H, W, C, C, OH, OW, 2), bias=bias, flags=ops.RELU)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), bias=bias, stride=2, padding=1).relu().permute(0, 2, 3, 1).reshape(M, Cout)
+    assert _rel(y[:, :Cout].float(), ref) < 4e-3
+    assert float(y[:, :Cout].float().min()) >= 0.0 and bool((y[:, Cout:] == 7.0).all())
+    assert float((ref == 0).float().mean()) > 0.05                      # the clamp is exercised
+    a = _rand(1024, 64, seed=4).bfloat16()
+    b = _rand(128, 64, seed=5).bfloat16()
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b, torch.empty(1024, 128, device="cuda", dtype=torch.bfloat16), flags=ops.RELU)                 # dense operand
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, wk, torch.empty(M, Cout, device="cuda"), M=M, amode=ops.A_CONV3, conv=(H, W, C, C, OH, OW, 2),
+                 flags=ops.RELU | ops.OUT_F32)                                                                          # f32 output
+
+
 @pytest.mark.parametrize("M,I,J", [(700, 16, 200), (5264, 8, 1536), (1000, 144, 32), (333, 72, 48)])
 def test_gemm_tn_dense(M, I, J):
     ops = _ops()

@@ -130,6 +130,33 @@ def test_graph_captured_inference_matches_eager():
         assert torch.equal(got, ref)
 
 
+def test_eval_batchnorm_fold_matches_the_unfolded_path_and_follows_the_running_statistics():
+    """in eval mode the ConvStream's BatchNorm is folded into its convolutions (scaled weights, shift
+    as bias, ReLU in the epilogue) and the fusion blocks' scale / shift are constants.  Same result as the unfolded path up to the bf16
+    rounding of the pre-activation it no longer stores; the fold is rebuilt when the running statistics change (a training forward)."""
+    cfg, p, model = _load("tiny", 128, 3, seed=11)
+    from oracle import synth_batch
+    x, _ = synth_batch(11, 3, 128, 3)
+    x = x.cuda()
+    eng = model._engine
+    model.eval()
+    with torch.no_grad():
+        eng.bn_fold = False
+        ref = model(x).clone()
+        eng.bn_fold = True
+        out = model(x).clone()
+        assert float(_chan_rel_mse(out, ref).max()) < 2e-4
+        assert torch.equal(model(x), out)                     # cached fold: same bits again
+        model.train()
+        model(x)                                              # train-mode BatchNorm: running statistics move
+        model.eval()
+        out2 = model(x).clone()
+        eng.bn_fold = False
+        ref2 = model(x).clone()
+    assert float(_chan_rel_mse(out2, ref2).max()) < 2e-4
+    assert float(_chan_rel_mse(out2, out).max()) > 1e-6       # the statistics did change the eval output: the fold followed them
+
+
 def test_512_tiles_ragged_tokens():
     """512x512 tiles (N = 36*36+5 = 1301 tokens, regrid 36->32): forward parity vs the oracle (BASELINE config 4 shape)."""
     from oracle import VIT_CONFIGS, det_state_dict, generator_forward, synth_batch
