@@ -663,8 +663,81 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+#ifdef MVIT_WS_MFMA32
+    // MEASUREMENT ONLY (results are wrong: the epilogues read the accumulators in the 16x16 layout): the K step of a full tile on
+    // v_mfma_f32_32x32x16_bf16 -- four sub-steps of four MFMAs, fragments double-buffered (32 registers instead of 64), the reads of
+    // the next sub-step one behind every MFMA, the stage hand-over after the second MFMA of the last sub-step.
+    if constexpr (TMc == 4) {
+      f32x16 c32[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c32[i][j][r] = 0.f;
+      const int fr32 = lane & 31, fh32 = lane >> 5;
+      unsigned a32[4], b32[4];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const unsigned sw = (unsigned)(((2 * sb + fh32) ^ ((fr32 >> 1) & 7)) << 4);
+        a32[sb] = (unsigned)(wave_m * 64 + fr32) * 128u + sw;
+        b32[sb] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + fr32) * 128u + sw;
+      }
+      bf16x8 ga[2][2], gb[2][2];
+      auto rd = [&](const char* base, int sb, int r, bf16x8 (&xa)[2], bf16x8 (&xb)[2]) __attribute__((always_inline)) {
+        if (r < 2) xa[r] = *(const bf16x8*)(base + a32[sb] + r * 4096);
+        else xb[r - 2] = *(const bf16x8*)(base + b32[sb] + (r - 2) * 4096);
+      };
+      {
+        const char* cur = smem + stage * BUF_BYTES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd(cur, 0, r, ga[0], gb[0]);
+      }
+      auto kstep32 = [&](auto more_tag) __attribute__((always_inline)) {
+        constexpr bool more = decltype(more_tag)::value;
+        const char* cur = smem + stage * BUF_BYTES;
+#pragma unroll
+        for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            c32[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[sb & 1][m >> 1], gb[sb & 1][m & 1], c32[m >> 1][m & 1], 0, 0, 0);
+            rd(cur, sb + 1, m, ga[(sb + 1) & 1], gb[(sb + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          c32[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1][m >> 1], gb[1][m & 1], c32[m >> 1][m & 1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // B(g)
+        __builtin_amdgcn_sched_barrier(0);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+        const char* nxt = smem + stage * BUF_BYTES;
+#pragma unroll
+        for (int m = 2; m < 4; ++m) {
+          c32[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1][m >> 1], gb[1][m & 1], c32[m >> 1][m & 1], 0, 0, 0);
+          if (more) {
+            rd(nxt, 0, 2 * (m - 2), ga[0], gb[0]);
+            rd(nxt, 0, 2 * (m - 2) + 1, ga[0], gb[0]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      for (int k = 0; k + 1 < nk; ++k) kstep32(std::true_type{});
+      kstep32(std::false_type{});
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = c32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + r];
+    } else
+#endif
+    {
     for (int k = 0; k + 1 < nk; ++k) kstep(std::true_type{});
     kstep(std::false_type{});
+    }
 #ifdef MVIT_WS_TIMING
     if (units_done == 0) WS_STAMP(3, WS_CYC())
 #endif
