@@ -32,6 +32,9 @@ struct f32x2 {
 __device__ __forceinline__ f32x2 operator*(const f32x2& a, const f32x2& b) { return {a.x * b.x, a.y * b.y}; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
 #endif
+#ifndef MVIT_ATTN_DKV_REV
+#define MVIT_ATTN_DKV_REV 1   // 0: the dK/dV kernel walks its XCD's pairs in the dQ kernel's order (measurement)
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int KVB = 64;          // keys per LDS tile
@@ -160,10 +163,15 @@ __device__ __forceinline__ void store_row_groups(bf16_t* row, int Dh, int half, 
 // pair-major order: the re-reads then hit that XCD's L2 instead of crossing the fabric once per row block
 // (forward: 130 MB -> one pass over q, k, v, o per launch).  Bijective for any block count.
 struct BlockXY { int x, y; };
+// REV: the XCD's run is walked backwards.  The dK/dV kernel runs right after the dQ kernel on the same q / k / v / dO tiles: started
+// from the end of the run, its first round of blocks meets the pairs the dQ kernel touched LAST, still in that XCD's L2, instead of
+// opening with a cold burst (its prologue was 26 % of a wave's cycles, profiles/r05_attn_timing.txt).
+template <bool REV = false>
 __device__ __forceinline__ BlockXY block_xy(const AttnDims& dm) {
   const int total = gridDim.x, L = blockIdx.x;
   const int q = total >> 3, r = total & 7, xcd = L & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+  const int loc = REV ? (q + (xcd < r ? 1 : 0)) - 1 - (L >> 3) : (L >> 3);
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   const int y = (int)fast_div((unsigned)wg, dm.nx, dm.nx_magic);
   return {wg - y * (int)dm.nx, y};
 }
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NRING][Q|dO] + L[Npad] + D[Npad] (f32)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const BlockXY bxy = block_xy(dm);
+  const BlockXY bxy = block_xy<MVIT_ATTN_DKV_REV>(dm);
   const int bh = bxy.y, b = (int)fast_div((unsigned)bh, (unsigned)dm.H, dm.h_magic), h = bh - b * dm.H;
   const int N = dm.N, Dh = dm.Dh;
   const size_t rs = (size_t)3 * dm.H * Dh, ors = (size_t)dm.H * Dh;
