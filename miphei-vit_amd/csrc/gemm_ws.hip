@@ -36,6 +36,12 @@ constexpr int NCW = 8, NPW = 4;                      // consumer / producer wave
 constexpr int PPW = (BM + BN) / 8 / NPW;             // DMA pieces (8 rows x 128 B) per producer wave per K tile = 12
 constexpr int PA = BM / 8 / NPW, PB = BN / 8 / NPW;  // of which A / B pieces: 8 + 4
 constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4;
+// The 16 MFMAs of a sub-step run in boustrophedon order over the wave's 4 x 4 accumulator blocks: every instruction shares one operand
+// fragment with its predecessor (A along a row, B at the row turns -- in plain row-major order both operands change at a turn).  The
+// loop is power-bound (docs/rounds/round5.md section 14): same cycles per K tile, launches 0.5-1 % shorter, step +0.4 % (section 17).
+#ifndef MVIT_WS_SNAKE
+#define MVIT_WS_SNAKE 1   // 0 (measurement): row-major order
+#endif
 constexpr int SLD = WTN + 4, SLAB = 16 * SLD;        // wave-private epilogue panel: 16 rows x 68 floats
 constexpr int V = 8;
 constexpr unsigned OOB = 0x80000000u;
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       const char* cur = smem + stage * BUF_BYTES;
 #pragma unroll
       for (int m = 0; m < TMc * TN; ++m) {
-        const int i = m / TN, j = m % TN;
+        const int i = m / TN, j = (MVIT_WS_SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
         if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
         else asm volatile("" ::"v"(fa[0][i]), "v"(fb[0][j]));
         if (!(MVIT_WS_ABLATE & 4)) {
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       constexpr int HO = TMc == 4 ? MVIT_WS_HO : 1;   // MFMAs of sub-step 1 ahead of the hand-over (measured: 2 / 6 / 10)
 #pragma unroll
       for (int m = 0; m < HO; ++m) {
-        const int i = m / TN, j = m % TN;
+        const int i = m / TN, j = (MVIT_WS_SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
         if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         else asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][j]));
         __builtin_amdgcn_sched_barrier(0);
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       const char* nxt = smem + stage * BUF_BYTES;
 #pragma unroll
       for (int m = HO; m < TMc * TN; ++m) {
-        const int i = m / TN, j = m % TN;
+        const int i = m / TN, j = (MVIT_WS_SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
         if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         else asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][j]));
         if (more && !(MVIT_WS_ABLATE & 4)) {
