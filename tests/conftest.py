@@ -16,6 +16,12 @@ if os.environ.get("MIPHEI_DBG_LIB") == "1":
     _mvit_lib.LIB_PATH = _mvit_lib.LIB_PATH.replace("libmiphei_hip.so", "libmiphei_hip_dbg.so")
 
 
+if os.environ.get("MIPHEI_LIB"):
+    # measurement runs only: the same tests against a compile-time variant of the library (make BUILD=... LIB=... EXTRA=-D...)
+    from miphei_vit_amd import _lib as _mvit_lib2
+    _mvit_lib2.LIB_PATH = os.path.abspath(os.environ["MIPHEI_LIB"])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
