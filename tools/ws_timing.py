@@ -79,18 +79,19 @@ def run(name, m, n, k, epi, warm_prev=None):
         endskew = (int(c_rt1.max()) - c_rt1).double() / 100.0
         nk = k // 64
         clk = (c_drain - c_c0).double() / ((c_rt1 - c_rt0).double() * 10.0)   # cycles per ns = GHz
+        first_req = med(p_iss - p_c0)
         rows[mode] = (sorted(ts)[len(ts) // 2], span, float(skew.max()), med(skew), med(p_land - p_c0), float((p_land - p_c0).max()),
                       med(c_first - c_c0), med(c_kend - c_first) / nk, med(c_epi - c_kend), med(c_drain - c_end), float(endskew.max()),
                       med(endskew), med(clk), nb)
         xcd = torch.arange(keep.shape[0], device=keep.device)[keep[:, 0] != 0] % 8
         dur = (c_rt1 - c_rt0).double() / 100.0
         rows[mode] = rows[mode] + ([round(float(dur[xcd == j].mean()), 1) for j in range(8)],
-                                   [round(float(clk[xcd == j].mean()), 3) for j in range(8)])
+                                   [round(float(clk[xcd == j].mean()), 3) for j in range(8)], first_req)
     for mode, r in rows.items():
         print(f"{name:9s} {mode}: event {r[0]:6.1f} us | span {r[1]:6.1f} | start skew max {r[2]:4.1f} med {r[3]:4.1f} us | first K tile landed "
               f"{r[4]:6.0f} cyc (max {r[5]:6.0f}) | consumer start->first tile {r[6]:6.0f} | K tile {r[7]:6.0f} cyc | epilogue issue {r[8]:6.0f} | "
               f"store drain {r[9]:6.0f} | end skew max {r[10]:4.1f} med {r[11]:4.1f} us | clock {r[12]:.2f} GHz | blocks {r[13]}\n"
-              f"          block duration by XCD (us) {r[14]} | clock by XCD (GHz) {r[15]}", flush=True)
+              f"          block duration by XCD (us) {r[14]} | clock by XCD (GHz) {r[15]} | producers' first request issued {r[16]:.0f} cyc after entry", flush=True)
 
 
 if __name__ == "__main__":
