@@ -6,7 +6,7 @@ A step = one ModelModule.training_step on one synthetic minibatch per rank: HIP 
 encoder with LoRA + ViTMatte decoder, bf16 MFMA / f32 accumulate), fused WeightedMSE, HIP backward, gradient
 all-reduce (RCCL) when N>1, global-norm clip + Adam.  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the instantiation with the
-largest share of the step in profiles/r04_kernel_stats_train.txt: the 256x128 MFMA GEMM with the plain store epilogue
+largest share of the step in profiles/r06_kernel_stats_train.txt: the 256x128 MFMA GEMM with the plain store epilogue
 -- qkv forward and the dgrad GEMMs, since round 4 the wave-specialised gemm_ws_kernel<STORE>; algorithmic flops /
 HIP-event durations recorded live on every fourth launch of ONE of the timed steps), `roofline_step` (whole step, algorithmic FLOPs of SURVEY.md 8d / wall time) and `cpu_baseline` (the CPU oracle =
 port of the reference arithmetic, timed on this host's cores on a bounded sample: 2 warm-ups + median of 5).
@@ -164,6 +164,9 @@ def dry_run(a, world, rank):
             self._flat = types.SimpleNamespace(flat=torch.full((L * per + ndec,), float(rank)),
                                                gflat=torch.randn(L * per + ndec, generator=g), n_lora=L * per)
             self._pack_key = "x"
+
+        def params_changed(self):
+            self._pack_key = None
 
         def _ensure_flat(self):
             return self._flat
@@ -357,6 +360,13 @@ def main(argv=None):
         for i in range(2):
             step(a.warmup + a.steps + i)
         kernels = ops.KPROBE.stop()
+    if a.probe and a.mode == "infer" and not unet:
+        # configs[4]: the same per-kernel leg on two extra EAGER forwards after the timed region (the captured graph cannot carry
+        # events): every dense GEMM and attention call of the inference forward with its algorithmic FLOPs
+        ops.KPROBE.start()
+        for i in range(2):
+            eng.forward(batches[i][0], train=False, bn_train=False)
+        kernels = ops.KPROBE.stop()
     overlap_probe = None
     if a.mode == "train" and a.comm_standin not in ("0", "") and hasattr(eng, "grad_buckets"):
         overlap_probe = comm_overlap_probe(a, mod, eng, sync, step, dev)
@@ -432,6 +442,17 @@ def main(argv=None):
                                "peak_sustained": SUSTAINED_BF16 / 1e12, "frac_of_sustained": round(ach / SUSTAINED_BF16, 4),
                                "note": "HIP events on the stream around every fourth launch of this kernel (`sampled_launches` of `launches`: its four "
                                        "shapes in their proportions) in the sampled timed step"}
+        if kernels and not probe["n"]:
+            # no in-region probe (inference: the timed region replays a graph): `roofline` = the kernel family with the largest
+            # share of the two extra eager forwards
+            key, v = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+            ach = v["flops"] / (v["ms"] * 1e-3)
+            res["roofline"] = {"bound": "mfma", "kernel": key, "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16, 4), "traffic": None,
+                               "launches": v["n"] // 2, "avg_launch_us": round(v["ms"] * 1e3 / v["n"], 2),
+                               "note": "dominant dense-GEMM family of the forward: HIP events around each of its calls on two eager "
+                                       "forwards after the timed (graph-replay) region; rocprofv3 table of this command: "
+                                       "profiles/r06_kernel_stats_infer_b64.txt"}
         if kernels:
             tot_ms = sum(v["ms"] for v in kernels.values())
             rk = []

@@ -9,6 +9,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmiphei_hip.so")
+# measurement builds (make -C miphei-vit_amd/csrc dbg, or BUILD=... LIB=variants/... EXTRA=-D...) live apart from the product library and
+# are only ever loaded by tools/ (or by pytest --variant-lib PATH): nothing in the package or the test suite reads the environment
+VARIANTS_DIR = os.path.join(_HERE, "csrc", "variants")
+DBG_LIB_PATH = os.path.join(VARIANTS_DIR, "libmiphei_hip_dbg.so")
 
 # enum mvit_epilogue
 EPI_STORE, EPI_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_STATS, EPI_DSWIGLU, EPI_DGELU = range(8)

@@ -296,3 +296,22 @@ def compose(config_dir, overrides=(), config_name="config"):
                                          f"prefix: '{key}={val}'\nOr add a second + to add or override '{key}': '++{key}={val}'")
         parent[parts[-1]] = val
     return _wrap(_resolve(cfg, cfg))
+
+
+def check_precision(value):
+    """``train.precision`` as the reference hands it to ``pl.Trainer(precision=...)`` (/root/reference/src/train.py:205-207; the
+    reference's shipped default is "16-mixed", /root/reference/configs/config.yaml:23).  The HIP training path has ONE arithmetic
+    mode: bf16 MFMA operands, f32 accumulation, f32 master parameters and optimiser state -- Lightning's "bf16-mixed".  Returns
+    "bf16-mixed"; "16-mixed" (fp16 autocast + GradScaler in the reference) is accepted with a warning because bf16 shares f32's
+    exponent range and needs no loss scaler; anything else (true half / full / double precision) is refused instead of ignored."""
+    import warnings
+    v = str(value).strip().lower()
+    if v in ("bf16-mixed", "bf16"):
+        return "bf16-mixed"
+    if v in ("16-mixed", "16"):
+        warnings.warn('train.precision="16-mixed": the MI355X training path computes in bf16-mixed (bf16 MFMA operands, f32 '
+                      'accumulation and master weights, no loss scaler); fp16 operands exist for evaluation only '
+                      '(generator.eval().cuda().half())', UserWarning, stacklevel=2)
+        return "bf16-mixed"
+    raise NotImplementedError(f"train.precision={value!r}: the MI355X training path is bf16-mixed only "
+                              '(accepted: "bf16-mixed", "16-mixed" with a warning)')

@@ -79,6 +79,13 @@ class HipEngine:
         self._fold_key = None
         self._saved = None
 
+    def params_changed(self):
+        """The trainable parameters were rewritten in place through the flat buffer (Adam step, a rank-0 broadcast): such writes do not
+        bump ``tensor._version``, so both derived caches -- the bf16 packs and the eval-mode BatchNorm fold, whose key would otherwise
+        come out identical -- are dropped explicitly."""
+        self._pack_key = None
+        self._fold_key = None
+
     @property
     def device(self):
         return next(self.model.parameters()).device
@@ -992,7 +999,7 @@ class HipEngine:
         ops.adam_clip_step(fl.flat, fl.gflat, fl.m, fl.v, w.sqn, float(lr), betas[0], betas[1], eps,
                            1.0 - betas[0] ** fl.step, 1.0 - betas[1] ** fl.step, float(max_norm),
                            nonfinite=self.nonfinite_flag())
-        self._pack_key = None  # parameters changed in place through the flat buffer
+        self.params_changed()  # parameters changed in place through the flat buffer
         return w.sqn
 
     def nonfinite_flag(self):

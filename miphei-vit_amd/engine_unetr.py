@@ -96,6 +96,9 @@ class UnetrEngine:
     def _pack_key(self, v):
         self._encoder_engine()._pack_key = v
 
+    def params_changed(self):
+        self._encoder_engine().params_changed()
+
     def nonfinite_flag(self):
         dev = self._encoder_engine()._require_gpu()
         if self._nonfinite is None or self._nonfinite.device != dev:
@@ -136,7 +139,7 @@ class UnetrEngine:
         for f in (fl, efl):
             ops.adam_clip_step(f.flat, f.gflat, f.m, f.v, w.sqn, float(lr), betas[0], betas[1], eps, 1.0 - betas[0] ** f.step,
                                1.0 - betas[1] ** f.step, float(max_norm), nonfinite=self.nonfinite_flag())
-        self._encoder_engine()._pack_key = None
+        self._encoder_engine().params_changed()
         return w.sqn
 
     def optimizer_state_dict(self):

@@ -67,7 +67,7 @@ class DataParallelSync:
         if self.exchange:
             for buf in self._buffers("param"):
                 dist.broadcast(buf, src=src, group=self.group)
-            self.engine._pack_key = None
+            self.engine.params_changed()
 
     def _issue(self, t):
         if t.numel():

@@ -26,13 +26,14 @@ sys.path.insert(0, ROOT)
 def main(argv):
     from miphei_vit_amd.synthetic import synthetic_batch, synthetic_init_
     from miphei_vit_amd.checkpoint import save_checkpoint_atomic, save_pruned_safetensors
-    from miphei_vit_amd.config import compose
+    from miphei_vit_amd.config import check_precision, compose
     from miphei_vit_amd.generators import get_generator
     from miphei_vit_amd.loss import WeightedMSELoss, marker_weights_from_file
     from miphei_vit_amd.models import ModelModule
     from miphei_vit_amd.trainer import DataParallelSync
 
     cfg = compose(os.path.join(ROOT, "configs"), argv)
+    check_precision(cfg.train.get("precision", "bf16-mixed"))
     # Config branches of the reference's train.py that switch the objective (src/train.py:118-150) and are NOT on this path
     # fail loudly instead of silently training with WeightedMSELoss
     losses = cfg.train.losses

@@ -150,3 +150,18 @@ def test_shipped_tree_composes_like_the_reference_command_lines():
     assert unetr.model.model_name == "unet_lora" and unetr.model.dropout == 0.1 and unetr.train.batch_size == 8
     base = compose(d)                                     # bare `python run.py`: smp-UNet + GAN recipe -> outside the path
     assert base.model.model_name == "unet" and base.train.gan_train is True
+
+
+def test_train_precision_is_checked_not_ignored():
+    """cfg.train.precision (reference: pl.Trainer(precision=...), src/train.py:205-207): bf16-mixed is the path's one mode, the
+    reference's shipped "16-mixed" is accepted with a warning, anything else raises."""
+    import warnings
+    from miphei_vit_amd.config import check_precision
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert check_precision("bf16-mixed") == "bf16-mixed"
+    with pytest.warns(UserWarning, match="bf16-mixed"):
+        assert check_precision("16-mixed") == "bf16-mixed"
+    for bad in ("32-true", "64-true", "16-true", "bf16-true"):
+        with pytest.raises(NotImplementedError):
+            check_precision(bad)

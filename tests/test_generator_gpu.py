@@ -157,6 +157,30 @@ def test_eval_batchnorm_fold_matches_the_unfolded_path_and_follows_the_running_s
     assert float(_chan_rel_mse(out2, out).max()) > 1e-6       # the statistics did change the eval output: the fold followed them
 
 
+def test_eval_batchnorm_fold_is_rebuilt_after_an_in_place_parameter_update():
+    """Adam (and a rank-0 broadcast) rewrite the parameters through the flat buffer, which tensor._version does not see: the sequence
+    train forward -> eval forward (fold cached) -> adam_step -> eval forward must not serve the old ConvStream fold."""
+    cfg, p, model = _load("tiny", 128, 3, seed=12)
+    from oracle import synth_batch
+    x, y = synth_batch(12, 3, 128, 3)
+    x, y = x.cuda(), y.cuda()
+    eng = model._engine
+    model.train()
+    out = model(x)
+    (out.float() - y).pow(2).mean().backward()
+    model.eval()
+    with torch.no_grad():
+        before = model(x).clone()                             # builds and caches the fold
+    eng.adam_step(lr=5e-2)
+    with torch.no_grad():
+        after = model(x).clone()
+        eng.bn_fold = False
+        ref = model(x).clone()
+        eng.bn_fold = True
+    assert float(_chan_rel_mse(after, ref).max()) < 2e-4
+    assert float(_chan_rel_mse(after, before).max()) > 1e-6   # the step did move the output
+
+
 def test_512_tiles_ragged_tokens():
     """512x512 tiles (N = 36*36+5 = 1301 tokens, regrid 36->32): forward parity vs the oracle (BASELINE config 4 shape)."""
     from oracle import VIT_CONFIGS, det_state_dict, generator_forward, synth_batch

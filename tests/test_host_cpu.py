@@ -209,6 +209,7 @@ class FakeEngine:                      # the exchange only touches the flat buff
         g = torch.Generator().manual_seed(100 + rank)
         self._flat = types.SimpleNamespace(flat=torch.full((n,), float(rank)), gflat=torch.randn(n, generator=g), n_lora=n_lora)
         self._pack_key = "x"
+    def params_changed(self): self._pack_key = None
     def _ensure_flat(self): return self._flat
     def grad_buckets(self): return self._flat.gflat[n_lora:], self._flat.gflat[:n_lora]
     def lora_blocks(self): return L

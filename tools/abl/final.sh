@@ -2,8 +2,8 @@
 # GPU test suite + smoke + the whole measurement pass, one box
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
-python -c "import ctypes; [ctypes.CDLL('miphei-vit_amd/'+n) for n in ('libmiphei_hip.so','libmiphei_hip_dbg.so','libmiphei_tm.so')]; print('libs load')" > $O/log.txt 2>&1
+python -c "import ctypes; ctypes.CDLL('miphei-vit_amd/libmiphei_hip.so'); print('lib loads')" > $O/log.txt 2>&1
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 >> $O/log.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> $O/log.txt 2>&1
-bash tools/bench_all.sh r05 > $O/bench_all.txt 2>&1
+bash tools/bench_all.sh r06 > $O/bench_all.txt 2>&1
 tail -5 $O/log.txt; tail -60 $O/bench_all.txt

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/parity_reps; mkdir -p $O; : > $O/log.txt
 for r in 1 2 3; do
-for L in miphei-vit_amd/libmiphei_hip.so miphei-vit_amd/libmiphei_ab_head.so; do
+for L in miphei-vit_amd/libmiphei_hip.so miphei-vit_amd/csrc/variants/libmiphei_ab_head.so; do
   MIPHEI_LIB=$L python3 tools/bench_lib.py --steps ${STEPS:-50} --warmup 10 --comm-standin 0 --cpu-repeats 1 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().split('\n')[-1]); p=d['parity']

@@ -6,7 +6,7 @@ python -c "import ctypes; [ctypes.CDLL('miphei-vit_amd/'+n) for n in ('libmiphei
 timeout 900 python -m pytest tests/test_attention_gpu.py -x -q >> $O/log.txt 2>&1
 for rep in 1 2; do
 for N in 329 1301; do
-  echo "head N=$N" >> $O/log.txt; MIPHEI_LIB=miphei-vit_amd/libmiphei_ab_head.so python tools/bench_attn.py $N ours >> $O/log.txt 2>&1
+  echo "head N=$N" >> $O/log.txt; MIPHEI_LIB=miphei-vit_amd/csrc/variants/libmiphei_ab_head.so python tools/bench_attn.py $N ours >> $O/log.txt 2>&1
   echo "new  N=$N" >> $O/log.txt; python tools/bench_attn.py $N ours >> $O/log.txt 2>&1
 done
 for R in 0 1 2 3; do

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/attn_lds; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-MIPHEI_LIB=$R/miphei-vit_amd/libmiphei_ab_head.so rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS --output-format csv -d $O/head -- python3 $R/tools/bench_attn.py 329 ours > /dev/null 2>&1
+MIPHEI_LIB=$R/miphei-vit_amd/csrc/variants/libmiphei_ab_head.so rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS --output-format csv -d $O/head -- python3 $R/tools/bench_attn.py 329 ours > /dev/null 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS --output-format csv -d $O/new -- python3 $R/tools/bench_attn.py 329 ours > /dev/null 2>&1
 cd $R
 python3 - <<'PY' > $O/summary.txt

@@ -6,7 +6,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from miphei_vit_amd import _lib
-_lib.LIB_PATH = _lib.LIB_PATH.replace("libmiphei_hip.so", "libmiphei_hip_dbg.so")
+_lib.LIB_PATH = _lib.DBG_LIB_PATH
 import miphei_vit_amd.ops as ops
 L = _lib
 B, N, H, Dh = 16, 329, 24, 64

@@ -6,7 +6,7 @@ from miphei_vit_amd import _lib
 if os.environ.get("MIPHEI_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["MIPHEI_LIB"])
 elif os.environ.get("MIPHEI_DBG_LIB") == "1":
-    _lib.LIB_PATH = _lib.LIB_PATH.replace("libmiphei_hip.so", "libmiphei_hip_dbg.so")
+    _lib.LIB_PATH = _lib.DBG_LIB_PATH
 import miphei_vit_amd.ops as ops
 B, N, H, Dh = 16, int(sys.argv[1]) if len(sys.argv) > 1 else 329, 24, 64
 qkv = torch.randn(B, N, 3, H, Dh, device="cuda").bfloat16()

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from miphei_vit_amd import _lib
 if os.environ.get("MIPHEI_DBG_LIB") == "1":
-    _lib.LIB_PATH = _lib.LIB_PATH.replace("libmiphei_hip.so", "libmiphei_hip_dbg.so")
+    _lib.LIB_PATH = _lib.DBG_LIB_PATH
 if os.environ.get("MIPHEI_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["MIPHEI_LIB"])
 import miphei_vit_amd.ops as ops

@@ -6,7 +6,7 @@ os.environ.setdefault("MIPHEI_DETERMINISTIC", "1")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from miphei_vit_amd import _lib
 if os.environ.get("MIPHEI_DBG_LIB") == "1":
-    _lib.LIB_PATH = _lib.LIB_PATH.replace("libmiphei_hip.so", "libmiphei_hip_dbg.so")
+    _lib.LIB_PATH = _lib.DBG_LIB_PATH
 import torch
 import bench
 from miphei_vit_amd.generators import get_vitmatte

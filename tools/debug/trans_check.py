@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from miphei_vit_amd import _lib
 if os.environ.get("MIPHEI_DBG_LIB") == "1":
-    _lib.LIB_PATH = _lib.LIB_PATH.replace("libmiphei_hip.so", "libmiphei_hip_dbg.so")
+    _lib.LIB_PATH = _lib.DBG_LIB_PATH
 import miphei_vit_amd.ops as ops
 def rel(a, b): return float((a.double() - b.double()).norm() / b.double().norm())
 def timeit(fn, it=30):
