@@ -739,6 +739,504 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #endif
 }
 
+
+// ------------------------------------------------------------------ backward in ONE pass per (batch, head) pair (round 6)
+// N <= 7 * 48 = 336 keys and Dh = 64: a whole pair fits one workgroup, so S and dP are formed ONCE (5 matmuls and one exp pass instead of
+// the 7 and 2 of the two kernels above), q / k / v / dO are read once, and there is one prologue instead of two.
+//   key wave w (one per 48 keys; K and V fragments, dK^T and dV^T accumulators in registers for the whole kernel), per 32-query step:
+//     X  S = Q K^T, dP = dO V^T          (A = Q / dO rows of the step's LDS tile, B = the resident fragments; v_mfma_f32_16x16x32_bf16)
+//     Y  P = exp2(S sc - L), dS = P (dP scale - D scale); dS -> LDS as bf16 [key][32 q]     (lane = key column, 4 query rows per tile)
+//     Z  dV^T += dO^T P, dK^T += Q^T dS  (A = transposing reads of the same tiles; P / dS stay in their lanes as B operands)
+//   dQ needs dS with the key axis as the MFMA k dimension, i.e. transposed across lanes AND summed over all key waves.  Instead of a
+//   cross-wave f32 reduction (1 MB of LDS partials per pair) the bf16 dS^T tile of a step (22 KB) is read back one step later by
+//   transposing reads and multiplied with K^T over ALL keys: a fixed summation order -- bit-identical from run to run, no atomics, no
+//   partials in HBM.  That product (W) belongs to the HELPER wave, which has the registers the key waves lack: it keeps the K^T operand
+//   fragments of all four 16-row d tiles (4 x 11 x 4 = 176 registers, read once from the K rows in LDS), so a step's eight dQ tiles cost
+//   44 transposing reads instead of the 352 of one tile per wave (the first version: LDS-bound, 1570 cycles per tile).  The helper also
+//   issues every DMA ([Q | dO | O | O residual] step tiles two steps ahead) and forms D = sum_d dO (O + residual) from the landed tile.
+//   One s_barrier per step.  The two waves of a SIMD (wave i and i + 4) run one phase apart -- group 0: X Y Z, group 1: Z(j - 1) X Y -- so
+//   that one's softmax (vector unit) sits beside the other's matrix products instead of MFMA beside MFMA and VALU beside VALU.
+// LDS: K rows 44 KB (after step 0: staging of the dK / dV rows) + two dS^T buffers 44 KB + four step-tile slots 64 KB + L, D 2.8 KB =
+// 155 KB: one workgroup per CU (512 threads, 2 waves per SIMD, <= 256 registers).  Swizzles: tools/debug/attn_fused_lds_banks.py.
+namespace fused {
+constexpr int KW = 48;                 // keys per key wave
+constexpr int MAXKW = 7;               // key waves (+ 1 helper = 512 threads)
+constexpr int QB = 32;                 // query rows per step
+constexpr int NSLOT = 4;               // ring of step tiles
+constexpr int TILE_B = QB * 128;       // one 32-row tile of Q, dO, O or O's residual
+constexpr int SLOT_B = 4 * TILE_B;
+constexpr int MAXK32 = 11;             // 32-key steps of the dQ product at 7 key waves
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2v;
+__device__ __forceinline__ v4s trd(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p); }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// -DMVIT_ATTN_TIMING (measurement build, tools/debug/attn_fused_timing.py): s_memtime stamps summed per wave and phase, written behind
+// the D values (the tool over-allocates `dsum`): 16 longs per wave
+#ifdef MVIT_ATTN_TIMING
+#define FST_DECL long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter(); const long long tstart = tlast;
+#define FST(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; }
+#define FST_WRITE(P, dm, wave, lane)                                                                                              \
+  if (lane == 0) {                                                                                                               \
+    long long* prof = (long long*)((P).Dv + (size_t)(dm).B * (dm).H * (dm).N) + ((size_t)blockIdx.x * 8 + wave) * 16;             \
+    for (int k = 0; k < 8; ++k) prof[k] = tsum[k];                                                                               \
+    prof[8] = tstart, prof[9] = (long long)__builtin_readcyclecounter();                                                         \
+    prof[10] = __builtin_amdgcn_s_getreg((8 << 11) | (0 << 6) | 20) /* XCC_ID */;                                                \
+  }
+#else
+#define FST_DECL
+#define FST(k)
+#define FST_WRITE(P, dm, wave, lane)
+#endif
+
+struct Ptrs {
+  const bf16_t *qb, *kb, *vb, *dob, *ob, *orb;
+  bf16_t* dq;       // dqkv row 0 of this batch element, q section of this head (k: + H*64, v: + 2*H*64)
+  const float* lse;
+  float* Dv;
+};
+
+// Step-tile DMA, shared by all waves: a tile is 16 pieces of 1 KB (4 matrices x 4 row groups of 8) and issuing one costs a wave 100-200
+// cycles, so wave w issues pieces w and w + 8 (row group w & 3 of matrices w >> 2 and (w >> 2) + 2: waves 0-3 Q and O, waves 4-7 dO and
+// O's residual) at the top of a step and waits for them (vmcnt) in front of the step's barrier.  Lane l of a piece fills (row 8 m + (l >> 3),
+// physical chunk l & 7) from source chunk (l & 7) ^ (((row >> 1) & 3) << 1); rows >= N come back as zeros through an out-of-range offset.
+struct TilePieces {
+  __amdgpu_buffer_rsrc_t r0, r1;
+  unsigned v0, v1;     // lane offsets inside a tile (bytes)
+  unsigned s0, s1;     // row strides (bytes)
+  int m, dst0, dst1;   // row group, LDS offsets inside a slot
+  bool on1;
+};
+__device__ __forceinline__ TilePieces tile_pieces(int w, int lane, const Ptrs& P, size_t rs, size_t ors) {
+  TilePieces t;
+  const int hi = (w >> 2) & 1;
+  t.m = w & 3;
+  const int row = 8 * t.m + (lane >> 3), c = (lane & 7) ^ (((row >> 1) & 3) << 1);
+  t.s0 = (unsigned)(hi ? ors : rs) * 2u, t.s1 = (unsigned)ors * 2u;
+  t.v0 = (unsigned)row * t.s0 + (unsigned)c * 16u;
+  t.v1 = (unsigned)row * t.s1 + (unsigned)c * 16u;
+  t.r0 = make_rsrc(hi ? P.dob : P.qb);
+  t.r1 = make_rsrc(hi ? (P.orb ? P.orb : P.ob) : P.ob);
+  t.on1 = !hi || P.orb != nullptr;
+  t.dst0 = hi * TILE_B + t.m * 1024;
+  t.dst1 = (2 + hi) * TILE_B + t.m * 1024;
+  return t;
+}
+template <bool FAST>
+__device__ __forceinline__ void issue_one(const TilePieces& t, char* RING, int j, int N, int lane) {
+  char* dst = RING + (j & (NSLOT - 1)) * SLOT_B;
+  const int q0 = QB * j;
+  const bool ok = q0 + 8 * t.m + (lane >> 3) < N;
+  unsigned o0 = ok ? t.v0 : 0x80000000u, o1 = ok ? t.v1 : 0x80000000u;
+  asm volatile("" : "+v"(o0), "+v"(o1));
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(t.r0, (lds_ptr)(dst + t.dst0), 16, o0, q0 * (int)t.s0, 0, 0);
+  if (FAST || t.on1) __builtin_amdgcn_raw_ptr_buffer_load_lds(t.r1, (lds_ptr)(dst + t.dst1), 16, o1, q0 * (int)t.s1, 0, 0);
+}
+
+// this wave's pieces of tile j: pair `wave` (precomputed), and with fewer than 8 waves the pairs wave + NW, wave + 2 NW, ... as well
+struct TileIssue {
+  TilePieces tp;
+  const Ptrs* P;
+  size_t rs, ors;
+  int wave, NW;
+};
+// FAST = 8 waves and a residual of O (the training shape): one pair per wave, no run-time conditions in the steady state
+template <bool FAST>
+__device__ __forceinline__ void issue_pieces(const TileIssue& ti, char* RING, int j, int N, int lane) {
+  issue_one<FAST>(ti.tp, RING, j, N, lane);
+  if constexpr (!FAST)
+    for (int pw = ti.wave + ti.NW; pw < 8; pw += ti.NW) issue_one<false>(tile_pieces(pw, lane, *ti.P, ti.rs, ti.ors), RING, j, N, lane);
+}
+
+template <bool FAST, bool KMASK, int GRP>
+__device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, int lane, const Ptrs& P, const AttnDims& dm, size_t rs,
+                                         const TileIssue& tp) {
+  FST_DECL
+  const int l15 = lane & 15, g = lane >> 4, N = dm.N;
+  char* DS = smem + NKR * 128;
+  char* RING = smem + NKR * 256;
+  const float* LD = (const float*)(RING + NSLOT * SLOT_B);
+  const int NQP = NQ * QB;
+  const float sc = dm.scale * LOG2E, scale = dm.scale;
+
+  // resident K / V fragments: B operand (column = key 48 w + 16 kt + l15, k = d = 32 ks + 8 g ..)
+  bf16x8 kf[3][2], vf[3][2];
+  float cinit[3];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    const int key = KW * wave + 16 * kt + l15;
+    cinit[kt] = key < N ? 0.f : -1e30f;      // S of a padding key starts at -1e30: P = exp2(-1e30 sc - L) = 0 with no masking instruction
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+      if (key < N) {
+        t = *(const uint4*)(P.kb + (size_t)key * rs + 32 * ks + 8 * g);
+        u = *(const uint4*)(P.vb + (size_t)key * rs + 32 * ks + 8 * g);
+      }
+      kf[kt][ks] = *(bf16x8*)&t;
+      vf[kt][ks] = *(bf16x8*)&u;
+    }
+  }
+  f32x4 dk[4][3], dv[4][3];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}, dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // lane constants of the step tile (32 rows x 128 B, 16-byte chunk c of row r at c ^ (((r >> 1) & 3) << 1))
+  const int swA = ((l15 >> 1) & 3) << 1;                                   // fragment reads: row 16 qt + l15
+  int offA[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) offA[ks] = l15 * 128 + (((4 * ks + g) ^ swA) << 4);
+  const int rowT = 4 * g + (l15 >> 2), swT = ((rowT >> 1) & 3) << 1;       // transposing reads: rows 4 g + (l15 >> 2) (+ 16)
+  int offT[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) offT[dt] = rowT * 128 + (((2 * dt + ((l15 & 3) >> 1)) ^ swT) << 4) + ((l15 & 1) << 3);
+  // dS^T rows of this wave's keys: [key][32 q] bf16, 8-byte slot s (4 queries) at s ^ ((key >> 1) & 7) = s ^ (l15 >> 1)
+  const int fds = l15 >> 1;
+  const int offW0 = (KW * wave + l15) * 64 + ((g ^ fds) << 3), offW1 = (KW * wave + l15) * 64 + (((4 + g) ^ fds) << 3);
+
+  union Frag { bf16x8 v; uint2 h[2]; } pb[3], dsb[3];
+  // X + Y, one 16-query half at a time: S, dP (A = Q / dO rows from LDS) -> P, dS -> packed bf16 halves of the B operands of dV / dK
+  // (k slots 0-3: q = 4 g + i, 4-7: q = 16 + 4 g + i) and of the dS^T rows; the f32 scores of only one half are ever live
+  auto XY = [&](int j) __attribute__((always_inline)) {
+    const char* Qs = RING + (j & (NSLOT - 1)) * SLOT_B;
+    const char* Gs = Qs + TILE_B;
+    char* DSj = DS + (j & 1) * NKR * 64;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x4 st[3], dp[3];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const float ci = KMASK ? cinit[kt] : 0.f;
+        st[kt] = (f32x4){ci, ci, ci, ci};
+        dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 aq = *(const bf16x8*)(Qs + qt * 2048 + offA[ks]);
+        const bf16x8 ag = *(const bf16x8*)(Gs + qt * 2048 + offA[ks]);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+          st[kt] = mfma16(aq, kf[kt][ks], st[kt]);
+          dp[kt] = mfma16(ag, vf[kt][ks], dp[kt]);
+        }
+      }
+      // rows q = 32 j + 16 qt + 4 g + r: L and D as one float4 each; padding rows carry L = 1e30, D = 0
+      const float4 L4 = *(const float4*)(LD + QB * j + 16 * qt + 4 * g), D4 = *(const float4*)(LD + NQP + QB * j + 16 * qt + 4 * g);
+      const f32x2 nL[2] = {{-L4.x, -L4.y}, {-L4.z, -L4.w}}, nD[2] = {{-D4.x, -D4.y}, {-D4.z, -D4.w}};
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const f32x2 x0 = fma2((f32x2){st[kt][0], st[kt][1]}, (f32x2){sc, sc}, nL[0]), x1 = fma2((f32x2){st[kt][2], st[kt][3]}, (f32x2){sc, sc}, nL[1]);
+        const f32x2 p0 = {__builtin_amdgcn_exp2f(x0.x), __builtin_amdgcn_exp2f(x0.y)}, p1 = {__builtin_amdgcn_exp2f(x1.x), __builtin_amdgcn_exp2f(x1.y)};
+        const f32x2 d0 = p0 * fma2((f32x2){dp[kt][0], dp[kt][1]}, (f32x2){scale, scale}, nD[0]);
+        const f32x2 d1 = p1 * fma2((f32x2){dp[kt][2], dp[kt][3]}, (f32x2){scale, scale}, nD[1]);
+        uint2 pw, dw;
+        pw.x = pack2bf(p0.x, p0.y), pw.y = pack2bf(p1.x, p1.y);
+        dw.x = pack2bf(d0.x, d0.y), dw.y = pack2bf(d1.x, d1.y);
+        pb[kt].h[qt] = pw;
+        dsb[kt].h[qt] = dw;
+        *(uint2*)(DSj + kt * 1024 + (qt ? offW1 : offW0)) = dw;
+      }
+    }
+  };
+  // Z: dV^T += dO^T P, dK^T += Q^T dS (A = transposing reads of the step tile)
+  auto Z = [&](int j) __attribute__((always_inline)) {
+    const char* Qs = RING + (j & (NSLOT - 1)) * SLOT_B;
+    const char* Gs = Qs + TILE_B;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8 ag = join(trd(Gs + offT[dt]), trd(Gs + offT[dt] + 2048));
+      const bf16x8 aq = join(trd(Qs + offT[dt]), trd(Qs + offT[dt] + 2048));
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        dv[dt][kt] = mfma16(ag, pb[kt].v, dv[dt][kt]);
+        dk[dt][kt] = mfma16(aq, dsb[kt].v, dk[dt][kt]);
+      }
+    }
+  };
+  // vmcnt(0): this wave's pieces of the tile two steps ahead have landed; lgkmcnt(0): s_barrier does not wait for LDS reads in flight
+  // (see the forward kernel's step)
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    FST(3)
+  };
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                            // K rows, step tiles 0 / 1, L are in LDS
+  __builtin_amdgcn_s_barrier();                                            // ... and D of block 0 (helper, from the landed tile 0)
+  FST(0)
+  if constexpr (GRP == 0) {
+    for (int j = 0; j < NQ; ++j) {
+      if (j + 2 < NQ) issue_pieces<FAST>(tp, RING, j + 2, N, lane);              // ring slot (j + 2) & 3 held tile j - 2, last read in step j - 1
+      XY(j);
+      FST(1)
+      Z(j);
+      FST(2)
+      bar();
+    }
+  } else {
+    if (2 < NQ) issue_pieces<FAST>(tp, RING, 2, N, lane);
+    XY(0);
+    FST(1)
+    bar();
+    for (int j = 1; j < NQ; ++j) {
+      if (j + 2 < NQ) issue_pieces<FAST>(tp, RING, j + 2, N, lane);
+      Z(j - 1);
+      FST(2)
+      XY(j);
+      FST(1)
+      bar();
+    }
+    Z(NQ - 1);
+    FST(2)
+  }
+  // dK / dV leave through LDS as full 128-byte rows: lane = key column with 4 consecutive d per accumulator -> [key][64 d] staging in
+  // this wave's 6 KB of the K-row region (dead since step 0: the helper holds K^T in registers) -> 16 bytes per lane, 8 lanes per row
+  {
+    char* stg = smem + wave * (KW * 128);
+    const size_t HD = (size_t)dm.H * 64;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const f32x4 a = m ? dv[dt][kt] : dk[dt][kt];
+          uint2 w;
+          w.x = pack2bf(a[0], a[1]), w.y = pack2bf(a[2], a[3]);
+          const int row = 16 * kt + l15, slot = (4 * dt + g) ^ (l15 & 15);           // 8-byte slot XOR row: conflict-free b64 writes
+          *(uint2*)(stg + row * 128 + (slot << 3)) = w;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int row = 8 * i + (lane >> 3), c = lane & 7;                          // 16-byte chunk c of the row = slots 2 c, 2 c + 1
+        const uint2 lo = *(const uint2*)(stg + row * 128 + (((2 * c) ^ (row & 15)) << 3));
+        const uint2 hi = *(const uint2*)(stg + row * 128 + (((2 * c + 1) ^ (row & 15)) << 3));
+        const int key = KW * wave + row;
+        if (key < N) *(uint4*)(P.dq + (size_t)key * rs + (1 + m) * HD + 8 * c) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+#ifdef MVIT_ATTN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FST(4)
+  FST_WRITE(P, dm, wave, lane)
+}
+
+// The helper: D and the dQ product with K^T held in registers.  FULL: the K dimension of that product is the compile-time 11 steps of 7
+// key waves (a run-time bound puts a branch around every step: each then waits for its own two reads -- 4400 cycles per query block
+// instead of 1500).
+template <bool FAST>
+__device__ __forceinline__ void helper_wave(char* smem, int NKR, int NQ, int wave, int lane, const Ptrs& P, const AttnDims& dm, size_t rs,
+                                            size_t ors, int bh, const TileIssue& tp) {
+  FST_DECL
+  const int N = dm.N;
+  const int l15 = lane & 15, g = lane >> 4, r4 = l15 >> 2, c4 = l15 & 3;
+  char* KS = smem;
+  char* DS = smem + NKR * 128;
+  char* RING = smem + NKR * 256;
+  float* LD = (float*)(RING + NSLOT * SLOT_B);
+  const int NQP = NQ * QB, nk32 = NKR >> 5;
+  constexpr bool FULL = FAST;
+  const bool has_res = FAST || P.orb != nullptr;
+  // D = sum_d dO (O + residual) of query block j from its landed tile: lane = (row l >> 1, column half l & 1), 3 x 4 reads of 16 bytes
+  auto d_block = [&](int j) __attribute__((always_inline)) {
+    const char* Gs = RING + (j & (NSLOT - 1)) * SLOT_B + TILE_B;
+    const int row = lane >> 1, sw = ((row >> 1) & 3) << 1;
+    float dsum = 0.f, dsum2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = row * 128 + (((4 * (lane & 1) + i) ^ sw) << 4);
+      const uint4 vg4 = *(const uint4*)(Gs + off), vo4 = *(const uint4*)(Gs + TILE_B + off);
+      uint4 vr4 = make_uint4(0, 0, 0, 0);
+      if (has_res) vr4 = *(const uint4*)(Gs + 2 * TILE_B + off);
+      const uint32_t ug[4] = {vg4.x, vg4.y, vg4.z, vg4.w}, uo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, ur[4] = {vr4.x, vr4.y, vr4.z, vr4.w};
+      // dO . O + dO . residual on v_dot2c_f32_bf16 (two bf16 products per instruction, f32 accumulate: products of bf16 are exact in f32)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dsum = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&uo[k], *(const bf2v*)&ug[k], dsum, false);
+        dsum2 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&ur[k], *(const bf2v*)&ug[k], dsum2, false);   // (no residual: zeros)
+      }
+    }
+    dsum += dsum2;
+    dsum += __shfl_xor(dsum, 1, 64);
+    const int q = QB * j + row;
+    if ((lane & 1) == 0) {
+      LD[NQP + q] = dsum * dm.scale;        // (padding rows: dO = 0 -> D = 0)
+      if (q < N) P.Dv[(size_t)bh * N + q] = dsum;
+    }
+  };
+  // K^T operand fragments of the dQ product (A: row = d 16 dt + l15, k = keys 32 ks2 + 8 g ..) from the K rows in LDS:
+  // 8-byte slot s of key k at s ^ (h(k) << 2), h = key bit 1 | key bit 3 << 1
+  bf16x8 afr[4][MAXK32];
+  auto load_afr = [&]() __attribute__((always_inline)) {
+    const int krow = 8 * g + r4, hk = ((r4 >> 1) & 1) | ((g & 1) << 1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const char* pa = KS + krow * 128 + (((4 * dt + c4) ^ (hk << 2)) << 3);
+#pragma unroll
+      for (int ks2 = 0; ks2 < MAXK32; ++ks2) {
+        v4s lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (FULL || ks2 < nk32) lo = trd(pa + ks2 * 4096), hi = trd(pa + ks2 * 4096 + 512);
+        afr[dt][ks2] = join(lo, hi);
+      }
+    }
+  };
+  // W: dQ^T (64 d x 32 q of query block jq) = K^T dS^T over all keys; dS^T rows [key][32 q] bf16, 8-byte slot s at s ^ ((key >> 1) & 7)
+  auto W = [&](int jq) __attribute__((always_inline)) {
+    const char* DSq = DS + (jq & 1) * NKR * 64;
+    const int krow = 8 * g + r4, f0 = 4 * (g & 1) + (r4 >> 1);               // (key >> 1) & 7 of the first read's row, + 2 for the second's
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const char* pb0 = DSq + krow * 64 + (((4 * qt + c4) ^ f0) << 3);
+      const char* pb1 = DSq + (krow + 4) * 64 + (((4 * qt + c4) ^ (f0 + 2)) << 3);
+      f32x4 acc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks2 = 0; ks2 < MAXK32; ++ks2) {
+        if (FULL || ks2 < nk32) {
+          const bf16x8 b = join(trd(pb0 + ks2 * 2048), trd(pb1 + ks2 * 2048));
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(afr[dt][ks2], b, acc[dt]);
+        }
+      }
+      const int q = QB * jq + 16 * qt + l15;
+      if (q < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; dt += 2) {     // lanes hold d rows 16 dt + 4 g ..: two d tiles = two 8-byte stores
+          uint2 w0, w1;
+          w0.x = pack2bf(acc[dt][0], acc[dt][1]), w0.y = pack2bf(acc[dt][2], acc[dt][3]);
+          w1.x = pack2bf(acc[dt + 1][0], acc[dt + 1][1]), w1.y = pack2bf(acc[dt + 1][2], acc[dt + 1][3]);
+          *(uint2*)(P.dq + (size_t)q * rs + 16 * dt + 4 * g) = w0;
+          *(uint2*)(P.dq + (size_t)q * rs + 16 * (dt + 1) + 4 * g) = w1;
+        }
+      }
+    }
+  };
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    FST(3)
+  };
+  for (int i = lane; i < NQP; i += 64) LD[i] = i < N ? P.lse[(size_t)bh * N + i] * LOG2E : 1e30f;   // padding rows: P = exp2(.. - 1e30) = 0
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                  // every wave's share of the K rows and of tiles 0 / 1 is in LDS
+  d_block(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  FST(0)
+  // step 0: the K^T fragments instead of a dQ product
+  if (2 < NQ) issue_pieces<FAST>(tp, RING, 2, N, lane);
+  if (NQ > 1) d_block(1);
+  load_afr();
+  FST(1)
+  bar();
+  int j = 1;
+  for (; j + 2 < NQ; ++j) {                                      // steady state: one basic block, so that the scheduler can put D's vector
+    issue_pieces<FAST>(tp, RING, j + 2, N, lane);                      // work between the MFMAs of W
+    d_block(j + 1);                                              // tile j + 1: issued in step j - 1, landed before that step's barrier
+    FST(1)
+    W(j - 1);
+    FST(2)
+    bar();
+  }
+  for (; j < NQ; ++j) {
+    if (j + 1 < NQ) d_block(j + 1);
+    FST(1)
+    W(j - 1);
+    FST(2)
+    bar();
+  }
+  W(NQ - 1);
+  FST(2)
+#ifdef MVIT_ATTN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FST(4)
+  FST_WRITE(P, dm, wave, lane)
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                                const bf16_t* __restrict__ ores, const bf16_t* __restrict__ dO,
+                                                                const float* __restrict__ lse, float* __restrict__ Dv,
+                                                                bf16_t* __restrict__ dqkv, AttnDims dm, int NKW) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.x, b = (int)fast_div((unsigned)bh, (unsigned)dm.H, dm.h_magic), h = bh - b * dm.H;
+  const int N = dm.N, NW = NKW + 1;
+  const int NKR = (NKW * KW + 31) & ~31, NQ = (N + QB - 1) / QB;
+  const size_t rs = (size_t)3 * dm.H * 64, ors = (size_t)dm.H * 64;
+  Ptrs P;
+  P.qb = qkv + (size_t)b * N * rs + (size_t)h * 64;
+  P.kb = P.qb + ors;
+  P.vb = P.kb + ors;
+  P.dob = dO + (size_t)b * N * ors + (size_t)h * 64;
+  P.ob = o + (size_t)b * N * ors + (size_t)h * 64;
+  P.orb = ores ? ores + (size_t)b * N * ors + (size_t)h * 64 : nullptr;
+  P.dq = dqkv + (size_t)b * N * rs + (size_t)h * 64;
+  P.lse = lse;
+  P.Dv = Dv;
+  // K rows -> LDS for the helper's K^T fragments (all waves share the 1 KB pieces): 8-byte slot s of key k at s ^ (h(k) << 2)
+  {
+    const __amdgpu_buffer_rsrc_t rK = make_rsrc(P.kb);
+    for (int m = wave; m < NKR / 8; m += NW) {
+      const int row = 8 * m + (lane >> 3);
+      const int hk = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      const int c = (lane & 7) ^ (hk << 1);
+      unsigned off = row < N ? ((unsigned)row * (unsigned)rs + (unsigned)c * 8u) * 2u : 0x80000000u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_ptr)(smem + m * 1024), 16, off, 0, 0, 0);
+    }
+    // rows of the dS^T buffers that no key wave writes (keys NKW * 48 .. NKR - 1): zero once, they are multiplied with zero K rows
+    char* DS = smem + NKR * 128;
+    const int pad0 = NKW * KW * 64, padn = (NKR - NKW * KW) * 64;
+    for (int i = tid * 16; i < padn; i += 512 * 16) {
+      *(uint4*)(DS + pad0 + i) = make_uint4(0, 0, 0, 0);
+      *(uint4*)(DS + NKR * 64 + pad0 + i) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  // step tiles 0 and 1
+  char* RING = smem + NKR * 256;
+  TileIssue tp;
+  tp.tp = tile_pieces(wave, lane, P, rs, ors);
+  tp.P = &P, tp.rs = rs, tp.ors = ors, tp.wave = wave, tp.NW = NW;
+  issue_pieces<FAST>(tp, RING, 0, N, lane);
+  if (NQ > 1) issue_pieces<FAST>(tp, RING, 1, N, lane);
+  // group 0 = the first half of the workgroup's waves, group 1 = the second half incl. the helper: waves i and i + 4 share a SIMD at 8 waves
+#ifdef MVIT_FUSED_NOGRP
+  const bool grp1 = false;      // (measurement: every key wave in the order X Y Z)
+#else
+  const bool grp1 = wave >= (NW + 1) / 2;
+#endif
+  if (wave == NKW) {
+#ifndef MVIT_FUSED_NOPRIO
+    // the helper is the youngest wave of its SIMD and the step's critical path (D, then all of W): without priority it loses every
+    // issue arbitration to the key wave beside it (priority outranks age)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    helper_wave<FAST>(smem, NKR, NQ, wave, lane, P, dm, rs, ors, bh, tp);
+  } else if (KW * (wave + 1) > N) {
+    if (grp1)
+      key_wave<FAST, true, 1>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+    else
+      key_wave<FAST, true, 0>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+  } else {
+    if (grp1)
+      key_wave<FAST, false, 1>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+    else
+      key_wave<FAST, false, 0>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+  }
+}
+}  // namespace fused
+
 }  // namespace
 
 static bool make_dims(AttnDims& dm, int B, int N, int H, int Dh, float scale) {
@@ -748,6 +1246,15 @@ static bool make_dims(AttnDims& dm, int B, int N, int H, int Dh, float scale) {
   if (total * dmax >= 0xffffffffull) return false;           // (fast_div's range; also keeps the 1-D grid far below its limit)
   dm = AttnDims{B, N, H, Dh, scale, nx, mvit_div_magic(nx), mvit_div_magic((unsigned)H)};
   return true;
+}
+
+// the one-pass backward takes every shape whose keys fit seven key waves; the two-kernel form keeps the rest (N = 1301 at 512 x 512 tiles)
+static bool fused_bwd_ok(int N, int Dh) {
+#ifdef MVIT_DEBUG_KNOBS
+  static const int knob = getenv("MVIT_ATTN_FUSED") ? atoi(getenv("MVIT_ATTN_FUSED")) : 1;   // measurement library: 0 = the two-kernel form
+  if (!knob) return false;
+#endif
+  return Dh == 64 && N <= fused::KW * fused::MAXKW;
 }
 
 extern "C" {
@@ -770,6 +1277,22 @@ MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* ou
   AttnDims dm;
   if (!make_dims(dm, B, N, H, Dh, scale)) return MVIT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (fused_bwd_ok(N, Dh)) {
+    // one workgroup per (batch, head) pair: S and dP once, q / k / v / dO read once, dQ reduced inside the block in a fixed order
+    const int NKW = (N + fused::KW - 1) / fused::KW, NKR = (NKW * fused::KW + 31) & ~31, NQP = ((N + fused::QB - 1) / fused::QB) * fused::QB;
+    const size_t lds = (size_t)NKR * 256 + (size_t)fused::NSLOT * fused::SLOT_B + 2 * (size_t)NQP * 4;
+    static mvit_per_device_size lds_raised_f[2];
+    const bool fast = NKW == fused::MAXKW && out_res != nullptr;      // 8 waves and a residual of O: the instantiation without run-time conditions
+    const void* fn = fast ? (const void*)fused::attn_bwd_fused_kernel<true> : (const void*)fused::attn_bwd_fused_kernel<false>;
+    if (mvit_ensure_dynamic_lds(fn, lds, lds_raised_f[fast]) != MVIT_OK) return MVIT_EINVAL;
+    if (fast)
+      hipLaunchKernelGGL(fused::attn_bwd_fused_kernel<true>, dim3(B * H), dim3(64 * (NKW + 1)), lds, s, (const bf16_t*)qkv, (const bf16_t*)out,
+                         (const bf16_t*)out_res, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm, NKW);
+    else
+      hipLaunchKernelGGL(fused::attn_bwd_fused_kernel<false>, dim3(B * H), dim3(64 * (NKW + 1)), lds, s, (const bf16_t*)qkv, (const bf16_t*)out,
+                         (const bf16_t*)out_res, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm, NKW);
+    return MVIT_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((N + 127) / 128) * B * H), dim3(256), NRING_Q * 2 * TILE_BYTES, s, (const bf16_t*)qkv,
                      (const bf16_t*)out, (const bf16_t*)out_res, (const bf16_t*)d_out, lse, dsum, (bf16_t*)dqkv, dm);
   const size_t lds_kv = (size_t)NRING * 2 * TILE_BYTES + 2 * (size_t)(((N + KVB - 1) / KVB) * KVB) * 4;

@@ -13,7 +13,12 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("B,N,H,Dh", [(2, 329, 3, 64), (1, 69, 4, 16), (2, 86, 3, 32), (1, 1301, 2, 64), (3, 128, 2, 64),
-                                       (2, 329, 24, 64)])      # the last one: H-Optimus-0's own head count (24-head stride pattern of the packed qkv)
+                                       (2, 329, 24, 64),       # H-Optimus-0's own head count (24-head stride pattern of the packed qkv)
+                                       # Dh = 64, N <= 336: the one-pass backward (one workgroup per (batch, head) pair, round 6) at its
+                                       # edges -- the largest N it takes and the first it leaves to the two-kernel form, one key wave, a
+                                       # single query step, key waves / query blocks that end exactly on and one past a boundary
+                                       (1, 336, 2, 64), (1, 337, 2, 64), (2, 48, 2, 64), (2, 49, 3, 64), (1, 7, 2, 64), (2, 32, 1, 64),
+                                       (1, 33, 2, 64), (2, 257, 12, 64), (1, 96, 2, 64), (1, 97, 2, 64), (1, 320, 2, 64), (1, 305, 2, 64)])
 def test_attention_fwd_bwd(B, N, H, Dh):
     import miphei_vit_amd.ops as ops
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + N)
