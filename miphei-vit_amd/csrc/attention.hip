@@ -754,8 +754,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 //   fragments of all four 16-row d tiles (4 x 11 x 4 = 176 registers, read once from the K rows in LDS), so a step's eight dQ tiles cost
 //   44 transposing reads instead of the 352 of one tile per wave (the first version: LDS-bound, 1570 cycles per tile).  The helper also
 //   issues every DMA ([Q | dO | O | O residual] step tiles two steps ahead) and forms D = sum_d dO (O + residual) from the landed tile.
-//   One s_barrier per step.  The two waves of a SIMD (wave i and i + 4) run one phase apart -- group 0: X Y Z, group 1: Z(j - 1) X Y -- so
-//   that one's softmax (vector unit) sits beside the other's matrix products instead of MFMA beside MFMA and VALU beside VALU.
+//   One s_barrier per step.  (Tried and dropped, docs/rounds/round6.md: three barrier-separated slots per step with the two waves of a SIMD
+//   one slot apart -- slower, the slots' maxima add up; the second half of the waves one phase behind (Z(j - 1) X Y) -- no difference.)
 // LDS: K rows 44 KB (after step 0: staging of the dK / dV rows) + two dS^T buffers 44 KB + four step-tile slots 64 KB + L, D 2.8 KB =
 // 155 KB: one workgroup per CU (512 threads, 2 waves per SIMD, <= 256 registers).  Swizzles: tools/debug/attn_fused_lds_banks.py.
 namespace fused {
@@ -849,7 +849,7 @@ __device__ __forceinline__ void issue_pieces(const TileIssue& ti, char* RING, in
     for (int pw = ti.wave + ti.NW; pw < 8; pw += ti.NW) issue_one<false>(tile_pieces(pw, lane, *ti.P, ti.rs, ti.ors), RING, j, N, lane);
 }
 
-template <bool FAST, bool KMASK, int GRP>
+template <bool FAST, bool KMASK>
 __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, int lane, const Ptrs& P, const AttnDims& dm, size_t rs,
                                          const TileIssue& tp) {
   FST_DECL
@@ -968,30 +968,13 @@ __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, 
   __builtin_amdgcn_s_barrier();                                            // K rows, step tiles 0 / 1, L are in LDS
   __builtin_amdgcn_s_barrier();                                            // ... and D of block 0 (helper, from the landed tile 0)
   FST(0)
-  if constexpr (GRP == 0) {
-    for (int j = 0; j < NQ; ++j) {
-      if (j + 2 < NQ) issue_pieces<FAST>(tp, RING, j + 2, N, lane);              // ring slot (j + 2) & 3 held tile j - 2, last read in step j - 1
-      XY(j);
-      FST(1)
-      Z(j);
-      FST(2)
-      bar();
-    }
-  } else {
-    if (2 < NQ) issue_pieces<FAST>(tp, RING, 2, N, lane);
-    XY(0);
+  for (int j = 0; j < NQ; ++j) {
+    if (j + 2 < NQ) issue_pieces<FAST>(tp, RING, j + 2, N, lane);          // ring slot (j + 2) & 3 held tile j - 2, last read in step j - 2
+    XY(j);
     FST(1)
-    bar();
-    for (int j = 1; j < NQ; ++j) {
-      if (j + 2 < NQ) issue_pieces<FAST>(tp, RING, j + 2, N, lane);
-      Z(j - 1);
-      FST(2)
-      XY(j);
-      FST(1)
-      bar();
-    }
-    Z(NQ - 1);
+    Z(j);
     FST(2)
+    bar();
   }
   // dK / dV leave through LDS as full 128-byte rows: lane = key column with 4 consecutive d per accumulator -> [key][64 d] staging in
   // this wave's 6 KB of the K-row region (dead since step 0: the helper holds K^T in registers) -> 16 bytes per lane, 8 lanes per row
@@ -1211,28 +1194,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   issue_pieces<FAST>(tp, RING, 0, N, lane);
   if (NQ > 1) issue_pieces<FAST>(tp, RING, 1, N, lane);
   // group 0 = the first half of the workgroup's waves, group 1 = the second half incl. the helper: waves i and i + 4 share a SIMD at 8 waves
-#ifdef MVIT_FUSED_NOGRP
-  const bool grp1 = false;      // (measurement: every key wave in the order X Y Z)
-#else
-  const bool grp1 = wave >= (NW + 1) / 2;
-#endif
   if (wave == NKW) {
-#ifndef MVIT_FUSED_NOPRIO
     // the helper is the youngest wave of its SIMD and the step's critical path (D, then all of W): without priority it loses every
-    // issue arbitration to the key wave beside it (priority outranks age)
+    // issue arbitration to the key wave beside it (priority outranks age): 67 -> 59 k cycles per pair
     __builtin_amdgcn_s_setprio(3);
-#endif
     helper_wave<FAST>(smem, NKR, NQ, wave, lane, P, dm, rs, ors, bh, tp);
   } else if (KW * (wave + 1) > N) {
-    if (grp1)
-      key_wave<FAST, true, 1>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
-    else
-      key_wave<FAST, true, 0>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+    key_wave<FAST, true>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
   } else {
-    if (grp1)
-      key_wave<FAST, false, 1>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
-    else
-      key_wave<FAST, false, 0>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+    key_wave<FAST, false>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
   }
 }
 }  // namespace fused

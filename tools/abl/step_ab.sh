@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box, interleaved A/B of the training step: library A (MIPHEI_LIB path, default the saved HEAD build) vs the working tree's product library
 cd $GRAFT_REPO_ROOT
-A=${1:-miphei-vit_amd/csrc/variants/libmiphei_ab_head.so}
+A=${1:-miphei-vit_amd/csrc/variants/libmiphei_base.so}
 O=gpurun_out/step_ab; mkdir -p $O; : > $O/log.txt
 python -c "import ctypes; [ctypes.CDLL(n) for n in ('miphei-vit_amd/libmiphei_hip.so','$A')]; print('libs load')" >> $O/log.txt 2>&1
 for r in 1 2 3; do
