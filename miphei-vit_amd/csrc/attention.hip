@@ -851,14 +851,39 @@ __device__ __forceinline__ void issue_pieces(const TileIssue& ti, char* RING, in
 
 template <bool FAST, bool KMASK>
 __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, int lane, const Ptrs& P, const AttnDims& dm, size_t rs,
-                                         const TileIssue& tp) {
+                                         const TileIssue& tp, int bh) {
   FST_DECL
   const int l15 = lane & 15, g = lane >> 4, N = dm.N;
   char* DS = smem + NKR * 128;
   char* RING = smem + NKR * 256;
-  const float* LD = (const float*)(RING + NSLOT * SLOT_B);
+  float* LD = (float*)(RING + NSLOT * SLOT_B);
   const int NQP = NQ * QB;
   const float sc = dm.scale * LOG2E, scale = dm.scale;
+  // FAST: D = sum_d dO (O + residual) is formed by key waves 0-3, 8 rows of the NEXT step's query block each (lane = row 8 w + (l >> 3),
+  // 16-byte chunk l & 7 of the landed dO / O / residual tiles: 3 reads, 8 v_dot2c_f32_bf16, 3 lane exchanges) at the top of a step, where
+  // the score registers are dead.  On the helper (the step's critical path: it also owns all of W) the same sum was 1400 cycles per step.
+  auto d_rows = [&](int j) __attribute__((always_inline)) {
+    const char* Gs = RING + (j & (NSLOT - 1)) * SLOT_B + TILE_B;
+    const int row = 8 * wave + (lane >> 3);
+    const int off = row * 128 + (((lane & 7) ^ (((row >> 1) & 3) << 1)) << 4);
+    const uint4 vg4 = *(const uint4*)(Gs + off), vo4 = *(const uint4*)(Gs + TILE_B + off), vr4 = *(const uint4*)(Gs + 2 * TILE_B + off);
+    const uint32_t ug[4] = {vg4.x, vg4.y, vg4.z, vg4.w}, uo[4] = {vo4.x, vo4.y, vo4.z, vo4.w}, ur[4] = {vr4.x, vr4.y, vr4.z, vr4.w};
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d0 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&uo[k], *(const bf2v*)&ug[k], d0, false);
+      d1 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&ur[k], *(const bf2v*)&ug[k], d1, false);
+    }
+    d0 += d1;
+    d0 += __shfl_xor(d0, 1, 64);
+    d0 += __shfl_xor(d0, 2, 64);
+    d0 += __shfl_xor(d0, 4, 64);
+    const int q = QB * j + row;
+    if ((lane & 7) == 0) {
+      LD[NQP + q] = d0 * scale;             // (padding rows: dO = 0 -> D = 0)
+      if (q < N) P.Dv[(size_t)bh * N + q] = d0;
+    }
+  };
 
   // resident K / V fragments: B operand (column = key 48 w + 16 kt + l15, k = d = 32 ks + 8 g ..)
   bf16x8 kf[3][2], vf[3][2];
@@ -966,10 +991,15 @@ __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, 
 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                            // K rows, step tiles 0 / 1, L are in LDS
-  __builtin_amdgcn_s_barrier();                                            // ... and D of block 0 (helper, from the landed tile 0)
+  if (FAST && wave < 4) {
+    d_rows(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                                            // ... and D of block 0 (from the landed tile 0)
   FST(0)
   for (int j = 0; j < NQ; ++j) {
     if (j + 2 < NQ) issue_pieces<FAST>(tp, RING, j + 2, N, lane);          // ring slot (j + 2) & 3 held tile j - 2, last read in step j - 2
+    if (FAST && wave < 4 && j + 1 < NQ) d_rows(j + 1);                     // tile j + 1 landed before the previous step's barrier
     XY(j);
     FST(1)
     Z(j);
@@ -1111,27 +1141,27 @@ __device__ __forceinline__ void helper_wave(char* smem, int NKR, int NQ, int wav
   for (int i = lane; i < NQP; i += 64) LD[i] = i < N ? P.lse[(size_t)bh * N + i] * LOG2E : 1e30f;   // padding rows: P = exp2(.. - 1e30) = 0
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                  // every wave's share of the K rows and of tiles 0 / 1 is in LDS
-  d_block(0);
+  if (!FAST) d_block(0);                                         // (FAST: key waves 0-3 form D)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   FST(0)
   // step 0: the K^T fragments instead of a dQ product
   if (2 < NQ) issue_pieces<FAST>(tp, RING, 2, N, lane);
-  if (NQ > 1) d_block(1);
+  if (!FAST && NQ > 1) d_block(1);
   load_afr();
   FST(1)
   bar();
   int j = 1;
   for (; j + 2 < NQ; ++j) {                                      // steady state: one basic block, so that the scheduler can put D's vector
     issue_pieces<FAST>(tp, RING, j + 2, N, lane);                      // work between the MFMAs of W
-    d_block(j + 1);                                              // tile j + 1: issued in step j - 1, landed before that step's barrier
+    if (!FAST) d_block(j + 1);                                   // tile j + 1: issued in step j - 1, landed before that step's barrier
     FST(1)
     W(j - 1);
     FST(2)
     bar();
   }
   for (; j < NQ; ++j) {
-    if (j + 1 < NQ) d_block(j + 1);
+    if (!FAST && j + 1 < NQ) d_block(j + 1);
     FST(1)
     W(j - 1);
     FST(2)
@@ -1197,12 +1227,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   if (wave == NKW) {
     // the helper is the youngest wave of its SIMD and the step's critical path (D, then all of W): without priority it loses every
     // issue arbitration to the key wave beside it (priority outranks age): 67 -> 59 k cycles per pair
-    __builtin_amdgcn_s_setprio(3);
+#ifndef MVIT_FUSED_HPRIO
+#define MVIT_FUSED_HPRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(MVIT_FUSED_HPRIO);
     helper_wave<FAST>(smem, NKR, NQ, wave, lane, P, dm, rs, ors, bh, tp);
   } else if (KW * (wave + 1) > N) {
-    key_wave<FAST, true>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+    key_wave<FAST, true>(smem, NKR, NQ, wave, lane, P, dm, rs, tp, bh);
   } else {
-    key_wave<FAST, false>(smem, NKR, NQ, wave, lane, P, dm, rs, tp);
+    key_wave<FAST, false>(smem, NKR, NQ, wave, lane, P, dm, rs, tp, bh);
   }
 }
 }  // namespace fused
