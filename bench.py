@@ -70,6 +70,10 @@ def parse_args(argv=None):
     ap.add_argument("--attn-residual", type=int, default=1, help="0: attention backward forms D from the bf16 output alone (A/B)")
     ap.add_argument("--lora-group", type=int, default=0, help="ViT blocks per batched LoRA weight-gradient launch (0 = engine default)")
     ap.add_argument("--lora-buckets", type=int, default=4, help="sub-buckets of the LoRA gradient all-reduce (N > 1)")
+    ap.add_argument("--decoder-bucket-split", type=int, default=1, help="N > 1: the decoder gradient bucket (18.9 MB) as this many all-reduces")
+    ap.add_argument("--nccl-max-nchannels", type=int, default=0, help="N > 1: NCCL_MAX_NCHANNELS for RCCL (0: leave the environment alone); "
+                    "fewer channels = fewer CUs held by the ring kernels beside the backward GEMMs")
+    ap.add_argument("--nccl-proto", default="", help="N > 1: NCCL_PROTO for RCCL (e.g. Simple, LL, LL128; empty: leave the environment alone)")
     ap.add_argument("--comm-standin", default="16,1000", help="train mode pre-flight, outside the timed region: BLOCKS,USEC of the "
                     "ring-kernel stand-in launched on a side stream at the five bucket-issue points (csrc/standin.hip); 0 = off")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL; gloo only with --dry")
@@ -240,6 +244,11 @@ def main(argv=None):
     dev = torch.device("cuda", local)
     force_ddp = os.environ.get("MIPHEI_FORCE_DDP", "0") == "1"  # run the RCCL exchange even on one rank (testing)
     if world > 1 or force_ddp:
+        # RCCL reads these at communicator creation: set them before init (every rank parses the same command line)
+        if a.nccl_max_nchannels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(a.nccl_max_nchannels)
+        if a.nccl_proto:
+            os.environ["NCCL_PROTO"] = a.nccl_proto
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -283,7 +292,7 @@ def main(argv=None):
     mod.update_pix_metrics = bool(a.metrics)
     sync = None
     if world > 1 or force_ddp:
-        sync = DataParallelSync(eng, force=force_ddp, lora_buckets=a.lora_buckets, timing=True)
+        sync = DataParallelSync(eng, force=force_ddp, lora_buckets=a.lora_buckets, timing=True, decoder_split=a.decoder_bucket_split)
         sync.broadcast_parameters(0)
         mod.grad_sync = sync
     batches = [synthetic_batch(1234 + rank * 1000 + i, a.batch, a.img, nc, dev) for i in range(4)]
@@ -409,6 +418,9 @@ def main(argv=None):
             res["exposed_comm_ms_per_step"] = None if comm[0] is None else round(comm[0], 4)
             res["comm_buckets"] = comm[1]      # per bucket: bytes, slack behind the backward pass, stall in finish()
             res["config"]["lora_buckets"] = a.lora_buckets
+            res["config"]["decoder_bucket_split"] = a.decoder_bucket_split
+            res["rccl_env"] = {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_PROTO", "NCCL_ALGO", "NCCL_NCHANNELS_PER_PEER")
+                               if k in os.environ}
     if a.mode == "infer":
         # p50 latency of one batch, measured after the throughput window with a sync per batch
         ts = []

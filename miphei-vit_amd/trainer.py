@@ -27,7 +27,7 @@ class DataParallelSync:
     ``begin_step``; without it ``finish`` scales the buffer); with ``timing`` on it brackets that wait with events: the time the
     compute stream was held back by communication."""
 
-    def __init__(self, engine, group=None, force=False, lora_buckets=4, timing=False, standin=None, hooks_only=False):
+    def __init__(self, engine, group=None, force=False, lora_buckets=4, timing=False, standin=None, hooks_only=False, decoder_split=1):
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.exchange = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path on one rank
@@ -39,6 +39,11 @@ class DataParallelSync:
         self.active = self.exchange or standin is not None or hooks_only
         self._side = None
         self.lora_buckets = max(1, int(lora_buckets))
+        # decoder_split = K: the decoder bucket (18.9 MB for MIPHEI-ViT) leaves as K contiguous all-reduces instead of one.  A knob
+        # for the first real multi-GPU run: a ring kernel holds its CUs for as long as its message lasts, and every wave-specialised
+        # GEMM launch that overlaps it runs a second round; K smaller messages trade per-call latency for
+        # shorter residency -- to be chosen from measurements together with NCCL_MAX_NCHANNELS / NCCL_PROTO (bench.py --gpus N).
+        self.decoder_split = max(1, int(decoder_split))
         self.timing = timing
         self.exposed_events = []
         self.bucket_events = []       # timing: per step [(bytes, issue event, finish-start event, wait-done event), ...] in issue order
@@ -88,7 +93,13 @@ class DataParallelSync:
     def decoder_ready(self):
         if self.active:
             dec, _ = self.engine.grad_buckets()
-            self._issue(dec)
+            k, n = self.decoder_split, dec.numel()
+            if k <= 1 or n < k:
+                self._issue(dec)
+            else:
+                edges = [round(i * n / k) for i in range(k + 1)]
+                for a, b in zip(edges[:-1], edges[1:]):
+                    self._issue(dec[a:b])
 
     def _lora_ranges(self):
         """{lowest block of a sub-bucket: slice of the LoRA gradient region}; blocks are contiguous in the flat layout."""

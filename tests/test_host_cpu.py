@@ -215,12 +215,13 @@ class FakeEngine:                      # the exchange only touches the flat buff
     def lora_blocks(self): return L
 eng = FakeEngine()
 ref = torch.stack([torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]).mean(0)
-for nb in (4, 1, 3, 64):
+for nb, ksplit in ((4, 1), (1, 1), (3, 3), (64, 7)):
     eng = FakeEngine()
-    sync = DataParallelSync(eng, lora_buckets=nb)
+    sync = DataParallelSync(eng, lora_buckets=nb, decoder_split=ksplit)
     sync.broadcast_parameters(0)
     assert torch.equal(eng._flat.flat, torch.zeros(n)) and eng._pack_key is None      # rank 0's parameters everywhere
     sync.decoder_ready()        # launched from inside backward once the decoder gradients exist
+    assert len(sync._work) == ksplit, (len(sync._work), ksplit)                       # the decoder bucket in `decoder_split` all-reduces
     issued = []
     for l in range(L - 1, -1, -1):  # encoder backward, block 39 -> 0: a sub-bucket goes out when its lowest block is done
         before = len(sync._work)
