@@ -402,16 +402,6 @@ MVIT_API int mvit_cell_means(const float* pred, const float* target, const void*
  * from the persistent GEMM launches of the data-parallel step. */
 MVIT_API int mvit_occupy_cus(int blocks, int usec, mvit_stream_t stream);
 
-/* ---------------------------------------------------------------- per-XCD speed (csrc/standin.hip, csrc/gemm_ws.hip; round 5) */
-/* Under a dense bf16 MFMA load the eight XCDs of an MI355X settle at clocks several per cent apart.  mvit_xcd_probe: `blocks`
- * workgroups (one per CU) run the same MFMA loop (iters x 16 instructions per wave) and write their own duration in 10 ns ticks of
- * the clock all CUs share to out[blocks]; workgroup L runs on XCD L % 8.  mvit_set_xcd_rank(rank8): rank8[x] = rank of XCD x
- * (a permutation of 0..7, 0 = fastest) for the CURRENT device; the wave-specialised GEMM then gives the band items of a ragged
- * launch (fc1 of timm's SwiGLUPacked MLP at batch 16: /root/reference/src/generators/foundation_models.py:53-57) to the fastest
- * XCDs first.  NULL restores the even spread.  Results never depend on the ranking.  Replaces nothing in the reference. */
-MVIT_API int mvit_xcd_probe(unsigned long long* out, int blocks, int iters, mvit_stream_t stream);
-MVIT_API int mvit_set_xcd_rank(const int* rank8);
-
 #ifdef __cplusplus
 }
 #endif

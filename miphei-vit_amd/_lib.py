@@ -115,8 +115,6 @@ SIGNATURES = {
     "mvit_cell_means": [vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mvit_adam_clip_step": [vp, vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, cf, vp, vp],
     "mvit_occupy_cus": [ci, ci, vp],
-    "mvit_xcd_probe": [vp, ci, ci, vp],
-    "mvit_set_xcd_rank": [vp],
 }
 
 _lib = None

@@ -8,7 +8,6 @@ namespace mvit_gemm {
 int gemm_num_cus() { return mvit_num_cus(); }
 bool ws_supported(const mvit_gemm_args& a);           // gemm_ws.hip: the wave-specialised 256x128 kernel (round 4)
 int launch_ws(const mvit_gemm_args& a, hipStream_t s, int band_knob, int resid_single_knob, int dsw_reg_knob, int pack_store_knob);
-int set_xcd_rank(const int* rank8);                   // gemm_ws.hip
 bool ws4_supported(const mvit_gemm_args& a);          // gemm_ws4.hip: the same pipeline with one 128x64 consumer wave per SIMD (plain bf16 stores)
 int launch_ws4(const mvit_gemm_args& a, hipStream_t s);
 }  // namespace mvit_gemm
@@ -103,12 +102,6 @@ static bool takes_ws(const mvit_gemm_args& a, int v) {
   return (ws_mask & bit) != 0;
 }
 
-// XCD ranking for the band items of the wave-specialised GEMM (gemm_ws.hip): rank8[x] = rank of XCD x, 0 = takes band items first;
-// NULL = back to the even spread.  The host measures the ranking (miphei_vit_amd/xcd.py) -- nothing here syncs or allocates.
-extern "C" MVIT_API int mvit_set_xcd_rank(const int* rank8) {
-  MVIT_CLEAR_ERROR();
-  return mvit_gemm::set_xcd_rank(rank8);
-}
 
 extern "C" MVIT_API int mvit_gemm_variant(const mvit_gemm_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return MVIT_EINVAL;

@@ -40,21 +40,6 @@ constexpr size_t gemm_lds_bytes() {
   return (size_t)gemm_stages(BM, BN) * (BM + BN) * 128;
 }
 
-// Build-time switches for A/B measurements (tools/gemm_ablate.py, tools/abl/compare_libs.sh); the defaults are the product:
-//   MVIT_ABLATE       bit 0 / 1 / 2: compile the operand DMA / the LDS fragment reads / the MFMAs out of the K step
-//   MVIT_GEMM_SEQ     0: the previous K step (hipcc-scheduled, sched_group_barrier hints) instead of the explicit order
-//   MVIT_GEMM_PIPE8   0: 8-wave tiles on the plain loop (fragments read per sub-step, no register double-buffering)
-//   MVIT_GEMM_PREISSUE 0: two-stage tiles issue their whole refill inside the K step
-//   MVIT_GEMM_HO      n: MFMAs of the last sub-step ahead of the hand-over
-#ifndef MVIT_ABLATE
-#define MVIT_ABLATE 0
-#endif
-#ifndef MVIT_GEMM_SEQ
-#define MVIT_GEMM_SEQ 1
-#endif
-#ifndef MVIT_GEMM_PREISSUE
-#define MVIT_GEMM_PREISSUE 1
-#endif
 #ifndef MVIT_GEMM_TRANS   // 1: dense tiles accumulate C^T (MFMA operands swapped) and store row-per-lane, no LDS panel
 #define MVIT_GEMM_TRANS 1
 #endif
@@ -99,12 +84,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
   constexpr int SLD = WTN + 4;                // epilogue panel row stride (floats)
   constexpr int SLAB = 16 * SLD;              // 16-row slab per wave
-#ifndef MVIT_GEMM_PIPE8
-#define MVIT_GEMM_PIPE8 1
-#endif
   // register-double-buffered fragment pipeline with an explicit instruction order: one wave per SIMD (4 waves, 128-row
-  // sub-tiles) and, with MVIT_GEMM_PIPE8, the 8-wave 256-row tiles too
-  constexpr bool PIPE = (NW == 4 && WTM == 128) || (MVIT_GEMM_PIPE8 && NW == 8 && BM == 256);
+  // sub-tiles) and the 8-wave 256-row tiles
+  constexpr bool PIPE = (NW == 4 && WTM == 128) || (NW == 8 && BM == 256);
   // Transposed accumulation: acc[i][j] holds D^T (lane = row of C, registers = 4-column groups), so the epilogue needs no
   // transposition through LDS: every lane post-processes and stores pieces of its own row.
   // (Measured and dropped for the epilogues with per-element operands -- residual, SwiGLU, d(SwiGLU): a lane per row means 64
@@ -112,7 +94,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // (Not on the 16x16x32 tiles: a v_permlane16_swap version of the row-per-lane store -- 64-byte row segments per instruction -- was
   // measured at 81.2 vs 77.6 us for qkv and -0.25 % on the step against the LDS panel.)
   constexpr bool TRANS = MVIT_GEMM_TRANS && AMODE == MVIT_A_DENSE && EPI == MVIT_EPI_STORE && !MI16;
-  static_assert(!MI16 || (MVIT_GEMM_SEQ && PIPE), "the 16x16x32 K step exists in the explicitly ordered pipeline only");
+  static_assert(!MI16 || PIPE, "the 16x16x32 K step exists in the explicitly ordered pipeline only");
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
   static_assert((size_t)NW * SLAB * 4 + (size_t)WAVES_M * BN * 8 <= (size_t)BUF_BYTES, "epilogue panel must fit one LDS buffer");
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -314,9 +296,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
   // loop spread the DMA issue of a K tile over its MFMA sub-steps
   auto issue_pieces_fast = [&](int t, int buf, auto p0_tag, auto p1_tag) __attribute__((always_inline)) {
     constexpr int P0 = decltype(p0_tag)::value, P1 = decltype(p1_tag)::value;
-#if MVIT_ABLATE & 1  // measurement build (tools/gemm_ablate.py): no operand DMA inside the pinned loop
-    return;
-#endif
     char* a = smem + buf * BUF_BYTES + wave_u * 8 * 128;
     char* b = a + A_BYTES;
     const int soff = t * (BK * 2);
@@ -421,13 +400,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         boff[s_] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + frag_row) * 128u + sw;
       }
       auto load_frags = [&](const char* a, const char*, int s_, bf16x8 (&xa)[TMH], bf16x8 (&xb)[TN]) __attribute__((always_inline)) {
-#if MVIT_ABLATE & 2  // measurement build: fragments stay whatever the first read left in the registers
-#pragma unroll
-        for (int i = 0; i < TMH; ++i) asm volatile("" : "=v"(xa[i]));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" : "=v"(xb[j]));
-        return;
-#endif
         const char* pa = a + aoff[s_];
         const char* pb = a + boff[s_];
 #pragma unroll
@@ -442,13 +414,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int i = 0; i < TMH; ++i) xa[i] = *(const bf16x8*)(pa + i * FSTRIDE);
       };
       auto mma = [&](const bf16x8 (&xa)[TMH], const bf16x8 (&xb)[TN], int h = 0) __attribute__((always_inline)) {
-#if MVIT_ABLATE & 4  // measurement build: operand movement only
-#pragma unroll
-        for (int i = 0; i < TMH; ++i) asm volatile("" ::"v"(xa[i]));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(xb[j]));
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < TMH; ++i)
 #pragma unroll
@@ -471,7 +436,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       __builtin_amdgcn_s_barrier();
       load_frags(smem + cb * BUF_BYTES, smem + cb * BUF_BYTES + A_BYTES, 0, fa[0], fb[0]);
       constexpr int PG = (LPT + 2) / 3;  // DMA pieces per sub-step
-#if MVIT_GEMM_SEQ
       // Explicit instruction order for the tight steps: every MFMA is followed by at most one or two companion operations
       // (a fragment read for the next sub-step, in the order the next sub-step consumes them, or one DMA piece of the
       // refill), and sched_barrier(0) keeps hipcc from regrouping them into bursts.
@@ -511,26 +475,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
 #pragma unroll
         for (int m = mf0; m < mf1; ++m) {
           const int i = m / TN, j = m % TN, ia = ch * TMH + i;
-#if MVIT_ABLATE & 4
-          asm volatile("" ::"v"(ca[i]), "v"(cbf[j]));
-#else
           acc[ia][j] = TRANS ? mfma1(cbf[j], ca[i], acc[ia][j]) : mfma1(ca[i], cbf[j], acc[ia][j]);
-#endif
 #pragma unroll
           for (int c = 0; c < TMH + TN + LPT; ++c) {
             if (c < C && c * NMr / C == m - mf0) {
               // DMA pieces evenly between the reads, or (last sub-step before the hand-over) after all of them
               const int before = reads_first ? (c < NR ? 0 : c - NR) : c * ND / C;
               if (reads_first ? c >= NR : (c + 1) * ND / C > before) {
-#if !(MVIT_ABLATE & 1)
                 issue_piece(dt, dbuf, p0 + before, tag);
-#endif
               } else {
                 const int r = c - before;
-#if MVIT_ABLATE & 2
-                if (r >= 0) {
-                } else
-#endif
                 if (r == 0)
                   na[0] = *(const bf16x8*)(pa);
                 else if (!rb)
@@ -557,11 +511,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         constexpr int NM = TMH * TN;
         // MFMAs of the last sub-step issued before the hand-over, so that its fragment reads have landed at the barrier and the
         // next tile's first fragments still get some MFMAs of lead (measured: 1 of 4 and 3 of 8 are the best splits)
-#ifdef MVIT_GEMM_HO
-        constexpr int HO = MVIT_GEMM_HO;
-#else
         constexpr int HO = NM * 3 / 8;
-#endif
         const int rt = t + NSTAGE - 1;  // tile of this step's refill, into buffer ib
         if constexpr (MI16 && AHALF == 2) {
           // two sub-steps x two A groups = four phases of TMH x TN MFMAs; the B fragments change with the sub-step only:
@@ -597,7 +547,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         cb = nb;
         ib = ib + 1 == NSTAGE ? 0 : ib + 1;
       };
-#endif
       auto kstep = [&](int t, auto tight_tag) __attribute__((always_inline)) {
         constexpr bool tight = decltype(tight_tag)::value;
         const char* a = smem + cb * BUF_BYTES;
@@ -666,10 +615,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
       int t = t_begin;
       if (AMODE == MVIT_A_DENSE) {
         const int t_tight = min(t_end, p.K / BK) - (NSTAGE - 1);
-#if MVIT_GEMM_SEQ
         if (t < t_tight) {
           set_piece_offsets(0);
-          if constexpr (MVIT_GEMM_PREISSUE && NSTAGE == 2) {  // (three stages have the lead anyway: measured 2 % slower there)
+          if constexpr (NSTAGE == 2) {  // (three stages have the lead anyway: measured 2 % slower there)
             if (t + 1 < t_tight) {
               kstep_seq(t++, std::false_type{}, std::true_type{});
               for (; t + 1 < t_tight; ++t) kstep_seq(t, std::true_type{}, std::true_type{});
@@ -678,9 +626,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
           }
           for (; t < t_tight; ++t) kstep_seq(t, std::false_type{}, std::false_type{});
         }
-#else
-        for (; t < t_tight; ++t) kstep(t, std::true_type{});
-#endif
       }
       for (; t < t_end; ++t) kstep(t, std::false_type{});
     } else {

@@ -39,9 +39,7 @@ constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4;
 // The 16 MFMAs of a sub-step run in boustrophedon order over the wave's 4 x 4 accumulator blocks: every instruction shares one operand
 // fragment with its predecessor (A along a row, B at the row turns -- in plain row-major order both operands change at a turn).  The
 // loop is power-bound (docs/rounds/round5.md section 14): same cycles per K tile, launches 0.5-1 % shorter, step +0.4 % (section 17).
-#ifndef MVIT_WS_SNAKE
-#define MVIT_WS_SNAKE 1   // 0 (measurement): row-major order
-#endif
+constexpr bool SNAKE = true;
 constexpr int SLD = WTN + 4, SLAB = 16 * SLD;        // wave-private epilogue panel: 16 rows x 68 floats
 constexpr int V = 8;
 constexpr unsigned OOB = 0x80000000u;
@@ -68,11 +66,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr int NPSEUDO = 4, PS_WAVE_BYTES = 16 * 256, PS_BYTES = NCW * PS_WAVE_BYTES, PS_PPW = PS_BYTES / 1024 / NPW;   // 8 pieces per producer wave
 constexpr int PANEL_BYTES = 16 * 64 * 4;
 static_assert(PS_BYTES + 4 * PANEL_BYTES <= BUF_BYTES, "pseudo tile + four panels must fit a stage");
-// measurement builds (make DEBUG_KNOBS=1 BUILD=build_aN LIB=../libmiphei_aN.so EXTRA=-DMVIT_WS_ABLATE=N; results are garbage):
-// bit 0 no operand DMA, bit 1 no MFMAs, bit 2 no fragment reads (tools/bench_ws_abl.py)
-#ifndef MVIT_WS_ABLATE
-#define MVIT_WS_ABLATE 0
-#endif
 // -DMVIT_WS_TIMING (measurement build, tools/ws_timing.py): wave 0 (consumer) and wave 8 (producer) of every block stamp the phases
 // of the block's FIRST work unit with s_memtime (shader cycles) and the block's begin / end with s_memrealtime (100 MHz, common to
 // all CUs) into p.stats (16 x 8 bytes per block): where the fixed cost of a launch goes (launch skew, operand cold start, epilogue)
@@ -99,10 +92,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
 struct WsExtra {
   unsigned grid_magic;       // mvit_div_magic(gridDim.x)
   unsigned pg_magic;         // mvit_div_magic(GROUP_M * tiles_n), tiles_n = N / BN (band mode: same tiles_n)
-  // band mode: which blocks take the band items.  0xffffffff: block L takes item L (items spread evenly over the XCDs).  Otherwise 4 bits
-  // per XCD = its rank (0 = takes items first): block L on XCD L % 8 takes item rank * (blocks / 8) + L / 8, so the XCDs ranked last --
-  // the ones the host measured SLOWEST (tools/xcd_speed.py: the eight XCDs settle at clocks +-5 % apart) -- run no item behind their tiles
-  unsigned xcd_rank;
 };
 // x / g for the group heights 1 .. 4
 __device__ __forceinline__ int div_small(int x, int g) {
@@ -157,8 +146,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
   const int nks = nk + NPS;                                                // ring steps per unit
   const int my_tiles = ((int)blockIdx.x < ord.ntiles) ? (int)mvit_fast_div((unsigned)(ord.ntiles - 1 - (int)blockIdx.x), gridDim.x, xp.grid_magic) + 1 : 0;
   int item_id = (int)blockIdx.x;
-  if (BAND && xp.xcd_rank != 0xffffffffu && (gridDim.x & 7) == 0)
-    item_id = (int)((xp.xcd_rank >> (4 * (blockIdx.x & 7))) & 15u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  // band items in XCD-CONTIGUOUS order (block L runs on XCD L % 8): the nq items of one tile column (same B panel) on one XCD.  Measured
+  // (fc1 + SwiGLU at batch 16): 122.4-128.8 us with the items spread evenly (item L on block L), 116.8-118.2 contiguous; ranking the XCDs
+  // by measured speed on top of that added nothing (round 5) and its per-device global state is gone (round 6)
+  if (BAND && (gridDim.x & 7) == 0) item_id = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
   const bool has_item = BAND && item_id < nq * ord.tiles_n;                        // band item of this block: column id / nq, quarter id % nq
   const int item_col = div_small(item_id, nq > 0 ? nq : 1);                        // (nq <= 4: the band is lower than a tile)
   const int item_m = rows_full + (item_id - item_col * (nq > 0 ? nq : 1)) * 64, item_n = item_col * BN;
@@ -242,7 +233,6 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     };
     // (generic lambda: the DMA builtin exists for the device target only, see gemm_kernel.hpp)
     auto issue = [&](int k, int stage, bool item, auto) __attribute__((always_inline)) {
-      if (MVIT_WS_ABLATE & 1) return;
       if constexpr (NPS > 0) {
         if (k >= nk) {           // pseudo tile k - nk: the 16-row slab (k - nk) of every consumer wave
           char* d = smem + stage * BUF_BYTES + pw * (2 * PS_WAVE_BYTES);
@@ -449,22 +439,6 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
             }
             r_cur = RES_PER_STEP;
           }
-#ifdef MVIT_WS_DSW_DUMMYVALU
-          // measurement build (results are garbage): the VALU work a producer-side factor computation would add to a plain ring step
-          // (16 operand pairs x (8 elements x ~11 VALU incl. 2 transcendental) spread over 14 steps ~= 100 VALU + 18 transcendental)
-          if constexpr (KC < 0 && SL < 0) {
-            f32x4 x = __builtin_bit_cast(f32x4, pre[0]);
-#pragma unroll
-            for (int it = 0; it < MVIT_WS_DSW_DUMMYVALU; ++it) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x[e] * -1.44f));
-                x[e] = x[e] * sg * (1.f + x[e] * (1.f - sg)) + sg;
-              }
-            }
-            pre[0] = __builtin_bit_cast(u32x4, x);
-          }
-#endif
           // in flight, oldest first: request of step g + 1 | operand loads of step g - 1 | request of step g + 2 | operand loads of step g
           if (req || SL >= 0) wait_allow(r_prev + pieces + r_cur);
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -629,25 +603,20 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       const char* cur = smem + stage * BUF_BYTES;
 #pragma unroll
       for (int m = 0; m < TMc * TN; ++m) {
-        const int i = m / TN, j = (MVIT_WS_SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
-        if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
-        else asm volatile("" ::"v"(fa[0][i]), "v"(fb[0][j]));
-        if (!(MVIT_WS_ABLATE & 4)) {
+        const int i = m / TN, j = (SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        {
 #pragma unroll
           for (int r = 0; r < NR; ++r)      // reads spread over the MFMAs: ceil((m + 1) NR / NM) issued by MFMA m
             if (r >= (m * NR + NM - 1) / NM && r < ((m + 1) * NR + NM - 1) / NM) read_sub(cur, 1, r, fa[1], fb[1]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#ifndef MVIT_WS_HO
-#define MVIT_WS_HO 6
-#endif
-      constexpr int HO = TMc == 4 ? MVIT_WS_HO : 1;   // MFMAs of sub-step 1 ahead of the hand-over (measured: 2 / 6 / 10)
+      constexpr int HO = TMc == 4 ? 6 : 1;   // MFMAs of sub-step 1 ahead of the hand-over (measured: 2 / 6 / 10)
 #pragma unroll
       for (int m = 0; m < HO; ++m) {
-        const int i = m / TN, j = (MVIT_WS_SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
-        if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
-        else asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][j]));
+        const int i = m / TN, j = (SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -657,10 +626,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
       const char* nxt = smem + stage * BUF_BYTES;
 #pragma unroll
       for (int m = HO; m < TMc * TN; ++m) {
-        const int i = m / TN, j = (MVIT_WS_SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
-        if (!(MVIT_WS_ABLATE & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
-        else asm volatile("" ::"v"(fa[1][i]), "v"(fb[1][j]));
-        if (more && !(MVIT_WS_ABLATE & 4)) {
+        const int i = m / TN, j = (SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        if (more) {
           constexpr int NM2 = NM - HO;
 #pragma unroll
           for (int r = 0; r < NR; ++r)
@@ -669,77 +637,6 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-#ifdef MVIT_WS_MFMA32
-    // MEASUREMENT ONLY (results are wrong: the epilogues read the accumulators in the 16x16 layout): the K step of a full tile on
-    // v_mfma_f32_32x32x16_bf16 -- four sub-steps of four MFMAs, fragments double-buffered (32 registers instead of 64), the reads of
-    // the next sub-step one behind every MFMA, the stage hand-over after the second MFMA of the last sub-step.
-    if constexpr (TMc == 4) {
-      f32x16 c32[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) c32[i][j][r] = 0.f;
-      const int fr32 = lane & 31, fh32 = lane >> 5;
-      unsigned a32[4], b32[4];
-#pragma unroll
-      for (int sb = 0; sb < 4; ++sb) {
-        const unsigned sw = (unsigned)(((2 * sb + fh32) ^ ((fr32 >> 1) & 7)) << 4);
-        a32[sb] = (unsigned)(wave_m * 64 + fr32) * 128u + sw;
-        b32[sb] = (unsigned)A_BYTES + (unsigned)(wave_n * WTN + fr32) * 128u + sw;
-      }
-      bf16x8 ga[2][2], gb[2][2];
-      auto rd = [&](const char* base, int sb, int r, bf16x8 (&xa)[2], bf16x8 (&xb)[2]) __attribute__((always_inline)) {
-        if (r < 2) xa[r] = *(const bf16x8*)(base + a32[sb] + r * 4096);
-        else xb[r - 2] = *(const bf16x8*)(base + b32[sb] + (r - 2) * 4096);
-      };
-      {
-        const char* cur = smem + stage * BUF_BYTES;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rd(cur, 0, r, ga[0], gb[0]);
-      }
-      auto kstep32 = [&](auto more_tag) __attribute__((always_inline)) {
-        constexpr bool more = decltype(more_tag)::value;
-        const char* cur = smem + stage * BUF_BYTES;
-#pragma unroll
-        for (int sb = 0; sb < 3; ++sb)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            c32[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[sb & 1][m >> 1], gb[sb & 1][m & 1], c32[m >> 1][m & 1], 0, 0, 0);
-            rd(cur, sb + 1, m, ga[(sb + 1) & 1], gb[(sb + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          c32[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1][m >> 1], gb[1][m & 1], c32[m >> 1][m & 1], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // B(g)
-        __builtin_amdgcn_sched_barrier(0);
-        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
-        const char* nxt = smem + stage * BUF_BYTES;
-#pragma unroll
-        for (int m = 2; m < 4; ++m) {
-          c32[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1][m >> 1], gb[1][m & 1], c32[m >> 1][m & 1], 0, 0, 0);
-          if (more) {
-            rd(nxt, 0, 2 * (m - 2), ga[0], gb[0]);
-            rd(nxt, 0, 2 * (m - 2) + 1, ga[0], gb[0]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      for (int k = 0; k + 1 < nk; ++k) kstep32(std::true_type{});
-      kstep32(std::false_type{});
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = c32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + r];
-    } else
-#endif
     {
     for (int k = 0; k + 1 < nk; ++k) kstep(std::true_type{});
     kstep(std::false_type{});
@@ -804,15 +701,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           for (int e = 0; e < V; ++e) {
             const float a_ = (e & 1) ? __uint_as_float(ua[e >> 1] & 0xffff0000u) : __uint_as_float(ua[e >> 1] << 16);
             const float b_ = (e & 1) ? __uint_as_float(ub[e >> 1] & 0xffff0000u) : __uint_as_float(ub[e >> 1] << 16);
-#ifdef MVIT_WS_DSW_NOMATH      // measurement build (results are garbage): the epilogue without the sigmoid algebra
-            da[e] = v[e] * a_;
-            db[e] = v[e] * b_;
-#else
             const float sg = sigmoidf_(a_);
             const float vs = v[e] * sg;
             da[e] = vs * b_ * (1.f + a_ * (1.f - sg));
             db[e] = vs * a_;
-#endif
           }
           const int row = m_base + wave_m * WTM + i * 16 + rl_;
           if (row < p.M) {
@@ -1064,40 +956,6 @@ bool ws_supported(const mvit_gemm_args& a) {
   return true;
 }
 
-// Per-device XCD ranking for the band items.  Default = the identity ranking: item rank * 32 + L / 8, i.e. the items in XCD-CONTIGUOUS
-// order -- the nq items of one tile column (same B panel) on one XCD, two XCDs without items.  Measured (tools/xcd_speed.py, fc1 + SwiGLU
-// at batch 16): 122.4-128.8 us with the items spread evenly (item L on block L), 116.8-118.2 with ANY contiguous placement; ranking the
-// XCDs by measured speed (mvit_xcd_probe + mvit_set_xcd_rank, miphei_vit_amd/xcd.py, opt-in) added nothing on a box whose XCDs were
-// +-2 % apart.
-static std::atomic<unsigned> g_xcd_rank[MVIT_MAX_DEVICES];
-static std::atomic<bool> g_xcd_rank_init{false};
-static unsigned xcd_rank_of_device(int even_knob) {
-  constexpr unsigned IDENTITY = 0x76543210u;
-  if (even_knob) return 0xffffffffu;                 // (measurement: item L on block L)
-  if (!g_xcd_rank_init.load(std::memory_order_acquire)) return IDENTITY;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return IDENTITY;
-  const unsigned v = g_xcd_rank[dev].load(std::memory_order_relaxed);
-  return v ? v : IDENTITY;          // (0 = never set for this device; a ranking is a permutation of 0 .. 7 and never packs to 0)
-}
-int set_xcd_rank(const int* rank8) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVICES) return MVIT_EINVAL;
-  unsigned v = 0, seen = 0;
-  if (rank8) {
-    for (int x = 0; x < 8; ++x) {
-      if (rank8[x] < 0 || rank8[x] > 7) return MVIT_EINVAL;
-      seen |= 1u << rank8[x];
-      v |= (unsigned)rank8[x] << (4 * x);
-    }
-    if (seen != 0xffu) return MVIT_EINVAL;          // a permutation of 0 .. 7
-  }
-  for (int d = 0; d < MVIT_MAX_DEVICES && !g_xcd_rank_init.load(std::memory_order_relaxed); ++d) g_xcd_rank[d].store(0u, std::memory_order_relaxed);
-  g_xcd_rank[dev].store(rank8 ? v : 0u, std::memory_order_relaxed);
-  g_xcd_rank_init.store(true, std::memory_order_release);
-  return MVIT_OK;
-}
-
 template <int EPI, bool BAND>
 static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + ws::BM - 1) / ws::BM) * (a.N / ws::BN);
@@ -1110,7 +968,6 @@ static int launch_ws_one(const mvit_gemm_args& a, hipStream_t s) {
   ws::WsExtra xp;
   xp.grid_magic = mvit_div_magic((unsigned)gx);
   xp.pg_magic = mvit_div_magic((unsigned)(MVIT_WS_GROUP_M * (a.N / ws::BN)));
-  xp.xcd_rank = xcd_rank_of_device(BAND ? (a.flags >> 17) & 1 : 0);
   hipLaunchKernelGGL(kern, dim3(gx), dim3(64 * (ws::NCW + ws::NPW)), lds, s, a, xp);
   return MVIT_LAUNCH_CHECK();
 }
