@@ -74,8 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--nccl-max-nchannels", type=int, default=0, help="N > 1: NCCL_MAX_NCHANNELS for RCCL (0: leave the environment alone); "
                     "fewer channels = fewer CUs held by the ring kernels beside the backward GEMMs")
     ap.add_argument("--nccl-proto", default="", help="N > 1: NCCL_PROTO for RCCL (e.g. Simple, LL, LL128; empty: leave the environment alone)")
-    ap.add_argument("--comm-standin", default="16,1000", help="train mode pre-flight, outside the timed region: BLOCKS,USEC of the "
-                    "ring-kernel stand-in launched on a side stream at the five bucket-issue points (csrc/standin.hip); 0 = off")
+    ap.add_argument("--comm-standin", default="0", help="opt-in (e.g. 16,1000) train mode pre-flight, outside the timed region: BLOCKS,USEC "
+                    "of the ring-kernel stand-in launched on a side stream at the five bucket-issue points (csrc/standin.hip); 0 = off (default "
+                    "since round 6: 39 untimed steps, and the delta it reports includes the tail the last stand-in exposes in finish())")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL; gloo only with --dry")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher / rendezvous / exchange / timing protocol on CPU")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch rendezvous port (0: pick a free one)")

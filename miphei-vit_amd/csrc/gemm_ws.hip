@@ -953,6 +953,10 @@ bool ws_supported(const mvit_gemm_args& a) {
   // 32-bit byte offsets inside a tile's descriptor range
   const long long maxld = a.lda > a.ldb ? a.lda : a.ldb;
   if (256ll * maxld * 2 >= 0x7fffffffll) return false;
+  // ... and inside the output / epilogue-operand ranges: the single-round residual path and the d(SwiGLU) operand build descriptor
+  // offsets from ldc (f32: x 4) and ldaux (f32 residual x 4, packed bf16 pre-activation x 2)
+  if (256ll * a.ldc * ((a.flags & MVIT_OUT_F32) ? 4 : 2) >= 0x7fffffffll) return false;
+  if (a.aux && 256ll * a.ldaux * (a.epi == MVIT_EPI_RESID ? 4 : 2) >= 0x7fffffffll) return false;
   return true;
 }
 

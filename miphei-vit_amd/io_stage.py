@@ -92,7 +92,7 @@ def export_uint8(pred):
 _PERM_CACHE: dict = {}
 
 
-def shuffled_indices(n0: int, count: int, n_tiles: int, seed: int = 0) -> torch.Tensor:
+def shuffled_indices(n0: int, count: int, n_tiles: int, seed: int = 0, device=None) -> torch.Tensor:
     """Tile indices of the global samples n0 .. n0 + count - 1 of a shuffled, endlessly repeated pass over `n_tiles` tiles.
 
     The reference's training DataLoader draws a fresh permutation per epoch (``shuffle=True, drop_last=True``,
@@ -102,21 +102,26 @@ def shuffled_indices(n0: int, count: int, n_tiles: int, seed: int = 0) -> torch.
     continuous: an epoch's tail is not dropped, a batch may straddle two epochs.)"""
     if n_tiles <= 0 or count < 0:
         raise ValueError("shuffled_indices: need n_tiles > 0 and count >= 0")
-    out = torch.empty(count, dtype=torch.int64)
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    parts = []
     i = 0
     while i < count:
         n = n0 + i
         epoch, pos = divmod(n, n_tiles)
-        key = (int(seed), int(epoch), int(n_tiles))
+        key = (int(seed), int(epoch), int(n_tiles), str(dev))
         perm = _PERM_CACHE.get(key)
         if perm is None:
             g = torch.Generator(device="cpu")
             g.manual_seed((int(seed) * 1000003 + int(epoch) * 7919 + 12345) & 0x7FFFFFFFFFFFFFFF)
-            perm = torch.randperm(n_tiles, generator=g)
+            # an epoch's permutation moves to `device` ONCE; a step then slices it there (no pageable host-to-device copy inside
+            # the step: such a copy waits for the whole stream and leaves the step's prologue launch-bound)
+            perm = torch.randperm(n_tiles, generator=g).to(dev)
             if len(_PERM_CACHE) > 4:
                 _PERM_CACHE.clear()
             _PERM_CACHE[key] = perm
         take = min(count - i, n_tiles - pos)
-        out[i:i + take] = perm[pos:pos + take]
+        parts.append(perm[pos:pos + take])
         i += take
-    return out
+    if not parts:
+        return torch.empty(0, dtype=torch.int64, device=dev)
+    return parts[0] if len(parts) == 1 else torch.cat(parts)

@@ -126,7 +126,7 @@ def main(argv):
     for i in range(start, steps):
         if augment is not None:
             n0 = (i * world + rank) * B
-            idx = shuffled_indices(n0, B, tiles[0].shape[0], int(cfg.train.get("seed") or 0)).to(dev)
+            idx = shuffled_indices(n0, B, tiles[0].shape[0], int(cfg.train.get("seed") or 0), device=dev)
             batch = augment(tiles[0][idx], tiles[1][idx], n0)
         else:
             x, y = synthetic_batch(1234 + rank * 1000 + i, B, S, nc, dev)
