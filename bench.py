@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--img", type=int, default=256)
     ap.add_argument("--mode", choices=["train", "infer", "embed"], default="train",
                     help="embed = encoder-only class-token embeddings (SURVEY.md 8f row 4, extract_embeddings.py)")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default=None, help="infer / embed modes: fp16 = the reference's evaluation "
+                    "convention generator.eval().cuda().half() on the fp16-operand library (default: embed fp16 -- the reference's "
+                    "extraction script calls .half() --, infer bf16; training is always bf16: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the timed CPU-oracle training step")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle (0: sweep 32 / 64 / 128 / all, report the best)")
@@ -224,6 +227,8 @@ def dry_run(a, world, rank):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse_args(argv)
+    if a.dtype is None:
+        a.dtype = "fp16" if a.mode == "embed" else "bf16"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -269,7 +274,9 @@ def main(argv=None):
         with torch.device(dev):
             emb_model = FOUNDATION_MODEL_REGISTRY[a.encoder](a.img, pretrained=False, global_pool="token")
         synthetic_init_(emb_model, seed=0)
-        emb_model = emb_model.eval().half()
+        emb_model = emb_model.eval()
+        if a.dtype == "fp16":
+            emb_model = emb_model.half()
     unet = a.generator == "unet_lora"
     if unet and a.mode == "embed":
         raise SystemExit("--generator unet_lora: train / infer modes only")
@@ -298,9 +305,13 @@ def main(argv=None):
         mod.grad_sync = sync
     batches = [synthetic_batch(1234 + rank * 1000 + i, a.batch, a.img, nc, dev) for i in range(4)]
 
+    if a.dtype == "fp16" and a.mode == "train":
+        raise SystemExit("--dtype fp16: infer / embed modes only (training needs fp32 master parameters and bf16 operands)")
     x16 = [b[0].half() for b in batches] if a.mode == "embed" else None
     if a.mode == "infer":
         model.eval()
+        if a.dtype == "fp16":
+            model.half()
         run_graph, x_static, _ = eng.capture_inference(a.batch) if a.graph else (None, None, None)
 
     def step(i):
@@ -398,7 +409,7 @@ def main(argv=None):
                    "embedding tiles/sec (encoder only, class token, fp16 in/out)" if a.mode == "embed" else "inference tiles/sec"),
         "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": a.dtype if a.mode != "train" else "bf16", "data": "synthetic",
         "config": {"workload": (f"UNETR baseline ({a.encoder} + LoRA r8, ViT pyramid + up-conv decoder, 16 heads) " if unet else
                                 f"MIPHEI-ViT ({a.encoder} ViT-g/14 + LoRA r8, ViTMatte decoder, 16 heads) ") + f"{a.mode} step, "
                                f"{a.img}x{a.img} tiles, per-GPU batch {a.batch} " +

@@ -4,8 +4,10 @@ The product path has no fallback: if the library is missing or a symbol is absen
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmiphei_hip.so")
@@ -117,28 +119,58 @@ SIGNATURES = {
     "mvit_occupy_cus": [ci, ci, vp],
 }
 
-_lib = None
+# Two product libraries from the same sources (csrc/Makefile): bf16 operands (training, BASELINE.json's precision) and IEEE fp16 operands
+# (`generator.eval().cuda().half()`, the reference's evaluation convention, /root/reference/evaluation/eval_orion.py:191, 214-215).
+# Which one a call reaches is a per-thread mode set by the engine for the duration of a forward pass (`operands("f16")`); everything
+# outside such a block is the bf16 library.
+LIB_PATH_F16 = os.path.join(_HERE, "libmiphei_hip_f16.so")
+_libs = {}
+_mode = threading.local()
+
+
+def operand_mode() -> str:
+    return getattr(_mode, "v", "bf16")
+
+
+def operand_torch_dtype():
+    import torch
+    return torch.float16 if operand_mode() == "f16" else torch.bfloat16
+
+
+@contextlib.contextmanager
+def operands(mode: str):
+    """`with operands("f16"):` -- every ops.* call of this thread goes to the fp16-operand library (16-bit tensors are torch.float16)."""
+    if mode not in ("bf16", "f16"):
+        raise ValueError(f"operand mode {mode!r}: 'bf16' or 'f16'")
+    prev = operand_mode()
+    _mode.v = mode
+    try:
+        yield
+    finally:
+        _mode.v = prev
 
 
 def lib():
-    """Load the HIP library once; fail loudly when it is missing (no CPU/PyTorch fallback)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    """The HIP library of the current operand mode, loaded once; fails loudly when it is missing (no CPU/PyTorch fallback)."""
+    mode = operand_mode()
+    handle = _libs.get(mode)
+    if handle is None:
+        path = LIB_PATH_F16 if mode == "f16" else LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The MI355X path has no fallback.")
         # torch must load ITS HIP runtime first: libmiphei_hip.so then binds to that same libamdhip64 instance (same
         # soname).  Loaded the other way round the process ends up with two runtimes and every launch on a torch stream
         # fails with hipErrorNoDevice.
         import torch  # noqa: F401
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = C.c_longlong if name.endswith(("_bytes", "_elems")) else C.c_int
-        _lib = handle
-    return _lib
+        _libs[mode] = handle
+    return handle
 
 
 def check(rc: int, what: str):

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
+        st[kt] = mvit_mfma32(a, qf[s], st[kt], 0, 0, 0);
       }
     }
     // online softmax (log2 domain): p = 2^(s*sc - m); the key mask only exists in the ragged-tile instantiation
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
       for (int dt = 0; dt < 2; ++dt) {
         const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
         const bf16x8 a = join(tr_read4(Vs, kbase, cb, lane), tr_read4(Vs, kbase + 8, cb, lane));
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[dt], 0, 0, 0);
+        oacc[dt] = mvit_mfma32(a, pb, oacc[dt], 0, 0, 0);
       }
     }
     }
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
         const float v0 = oacc[dt][4 * g] * inv, v1 = oacc[dt][4 * g + 1] * inv, v2 = oacc[dt][4 * g + 2] * inv, v3 = oacc[dt][4 * g + 3] * inv;
         wo[dt][g].x = pack2bf(v0, v1);
         wo[dt][g].y = pack2bf(v2, v3);
-        wr[dt][g].x = pack2bf(v0 - __uint_as_float(wo[dt][g].x << 16), v1 - __uint_as_float(wo[dt][g].x & 0xffff0000u));
-        wr[dt][g].y = pack2bf(v2 - __uint_as_float(wo[dt][g].y << 16), v3 - __uint_as_float(wo[dt][g].y & 0xffff0000u));
+        wr[dt][g].x = pack2bf(v0 - lo16f(wo[dt][g].x), v1 - hi16f(wo[dt][g].x));
+        wr[dt][g].y = pack2bf(v2 - lo16f(wo[dt][g].y), v3 - hi16f(wo[dt][g].y));
       }
     const size_t ro = ((size_t)b * N + (q < N ? q : 0)) * ((size_t)dm.H * Dh) + (size_t)h * Dh;
     store_row_groups(out + ro, Dh, half, wo, q < N);
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     const uint32_t ua[4] = {ov.x, ov.y, ov.z, ov.w}, uc[4] = {u.x, u.y, u.z, u.w}, ur[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      dsum += (__uint_as_float(ua[j] << 16) + __uint_as_float(ur[j] << 16)) * __uint_as_float(uc[j] << 16);
-      dsum += (__uint_as_float(ua[j] & 0xffff0000u) + __uint_as_float(ur[j] & 0xffff0000u)) * __uint_as_float(uc[j] & 0xffff0000u);
+      dsum += (lo16f(ua[j]) + lo16f(ur[j])) * lo16f(uc[j]);
+      dsum += (hi16f(ua[j]) + hi16f(ur[j])) * hi16f(uc[j]);
     }
   }
   dsum += __shfl_xor(dsum, 32, 64);  // the other half of the head dimension
@@ -487,9 +487,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const bf16x8 a = *(const bf16x8*)(Ks + swz(32 * kt + l31, 2 * s + half));
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st, 0, 0, 0);
+          st = mvit_mfma32(a, qf[s], st, 0, 0, 0);
           const bf16x8 v = *(const bf16x8*)(Vs + swz(32 * kt + l31, 2 * s + half));
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, dof[s], dp, 0, 0, 0);
+          dp = mvit_mfma32(v, dof[s], dp, 0, 0, 0);
         }
         // dS^T = P (dP - D) scale, two scores per packed VALU instruction
         const f32x2 sc2 = {sc, sc}, nL2 = {-Lq, -Lq}, s2 = {dm.scale, dm.scale}, nD2 = {-Dq * dm.scale, -Dq * dm.scale};
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
           for (int dt = 0; dt < 2; ++dt) {
             const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
             const bf16x8 a = join(tr_read4(Ks, kbase, cb, lane), tr_read4(Ks, kbase + 8, cb, lane));
-            dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb, dqacc[dt], 0, 0, 0);
+            dqacc[dt] = mvit_mfma32(a, dsb, dqacc[dt], 0, 0, 0);
           }
         }
       }
@@ -650,9 +650,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const bf16x8 a = *(const bf16x8*)(Qs + swz(32 * qt + l31, 2 * s + half));
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], st, 0, 0, 0);
+          st = mvit_mfma32(a, kf[s], st, 0, 0, 0);
           const bf16x8 g = *(const bf16x8*)(Ds + swz(32 * qt + l31, 2 * s + half));
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, vf[s], dp, 0, 0, 0);
+          dp = mvit_mfma32(g, vf[s], dp, 0, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -682,9 +682,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
           for (int dt = 0; dt < 2; ++dt) {
             const int cb = 32 * dt + 16 * ((lane >> 4) & 1);
             const bf16x8 a = join(tr_read4(Ds, qbase, cb, lane), tr_read4(Ds, qbase + 8, cb, lane));
-            dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, dvacc[dt], 0, 0, 0);
+            dvacc[dt] = mvit_mfma32(a, pb, dvacc[dt], 0, 0, 0);
             const bf16x8 a2 = join(tr_read4(Qs, qbase, cb, lane), tr_read4(Qs, qbase + 8, cb, lane));
-            dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb, dkacc[dt], 0, 0, 0);
+            dkacc[dt] = mvit_mfma32(a2, dsb, dkacc[dt], 0, 0, 0);
           }
         }
       }
@@ -768,9 +768,8 @@ constexpr int SLOT_B = 4 * TILE_B;
 constexpr int MAXK32 = 11;             // 32-key steps of the dQ product at 7 key waves
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf2v;
 __device__ __forceinline__ v4s trd(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p); }
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return mvit_mfma16(a, b, c, 0, 0, 0); }
 
 // -DMVIT_ATTN_TIMING (measurement build, tools/debug/attn_fused_timing.py): s_memtime stamps summed per wave and phase, written behind
 // the D values (the tool over-allocates `dsum`): 16 longs per wave
@@ -871,8 +870,8 @@ __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, 
     float d0 = 0.f, d1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      d0 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&uo[k], *(const bf2v*)&ug[k], d0, false);
-      d1 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&ur[k], *(const bf2v*)&ug[k], d1, false);
+      d0 = mvit_dot2(uo[k], ug[k], d0);
+      d1 = mvit_dot2(ur[k], ug[k], d1);
     }
     d0 += d1;
     d0 += __shfl_xor(d0, 1, 64);
@@ -1073,8 +1072,8 @@ __device__ __forceinline__ void helper_wave(char* smem, int NKR, int NQ, int wav
       // dO . O + dO . residual on v_dot2c_f32_bf16 (two bf16 products per instruction, f32 accumulate: products of bf16 are exact in f32)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        dsum = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&uo[k], *(const bf2v*)&ug[k], dsum, false);
-        dsum2 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2v*)&ur[k], *(const bf2v*)&ug[k], dsum2, false);   // (no residual: zeros)
+        dsum = mvit_dot2(uo[k], ug[k], dsum);
+        dsum2 = mvit_dot2(ur[k], ug[k], dsum2);   // (no residual: zeros)
       }
     }
     dsum += dsum2;

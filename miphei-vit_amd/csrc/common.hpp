@@ -11,16 +11,51 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define MVIT_OK 0
 #define MVIT_EINVAL (-1)
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-
-// fp32 -> bf16, round-to-nearest-even, on the gfx950 hardware converter (one v_cvt_pk_bf16_f32 per pair)
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// ---- the 16-bit operand type.  Every kernel stores its GEMM / convolution / attention operands as raw 16-bit patterns (`bf16_t`,
+// fragments as `bf16x8`) and touches their VALUE only through the helpers below; the product library is built with bf16 operands
+// (BASELINE.json's precision).  -DMVIT_F16 builds the same sources with IEEE fp16 operands on v_mfma_f32_*_f16 (libmiphei_hip_f16.so):
+// the arithmetic type of the reference's evaluation convention `generator.eval().cuda().half()`
+// (/root/reference/evaluation/eval_orion.py:191, 214-215), selected by the engine when the module's parameters are fp16 -- without it
+// an fp16 model's weights were rounded a second time (fp16 -> bf16).
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#ifdef MVIT_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 op16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 op16x2_t;
+// low / high 16-bit operand of a packed word as f32
+__device__ __forceinline__ float lo16f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float hi16f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
+// fp32 pair -> packed operands, round-to-nearest-even (one v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  const op16x2_t r = __builtin_convertvector(v, op16x2_t);
+  return __builtin_bit_cast(uint32_t, r);
+}
+#define MVIT_ONE2 0x3c003c00u          /* two packed 1.0 */
+// c + a.lo * b.lo + a.hi * b.hi on packed operand words (v_dot2_f32_f16)
+__device__ __forceinline__ float mvit_dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(op16x2_t, a), __builtin_bit_cast(op16x2_t, b), c, false);
+}
+#define mvit_mfma16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(op16x8_t, a), __builtin_bit_cast(op16x8_t, b), c, x, y, z)
+#define mvit_mfma32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(op16x8_t, a), __builtin_bit_cast(op16x8_t, b), c, x, y, z)
+#else
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float lo16f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// fp32 -> bf16, round-to-nearest-even, on the gfx950 hardware converter (one v_cvt_pk_bf16_f32 per pair)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
   return *(const uint32_t*)&r;
 }
+#define MVIT_ONE2 0x3f803f80u
+// c + a.lo * b.lo + a.hi * b.hi on packed operand words (v_dot2c_f32_bf16)
+__device__ __forceinline__ float mvit_dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+#define mvit_mfma16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#define mvit_mfma32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#endif
+__device__ __forceinline__ float bf2f(bf16_t v) { return lo16f((uint32_t)v); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void conv3x3_chunked_kernel(const CcArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
               const bf16x8 wa = *(const bf16x8*)(ws + ((size_t)((ky * 3 + kx) * CC_NS + nt * 32 + l31) * CC_WROW + kk * 16 + half * 8) * 2);
-              acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[ky], acc[0][nt], 0, 0, 0);
-              acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[ky + 1], acc[1][nt], 0, 0, 0);
+              acc[0][nt] = mvit_mfma32(wa, xb[ky], acc[0][nt], 0, 0, 0);
+              acc[1][nt] = mvit_mfma32(wa, xb[ky + 1], acc[1][nt], 0, 0, 0);
             }
           }
         }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv3x3_chunked_wgrad_kernel(const
         const int prow = (s_ >> 1) + ky, pcol = 16 * (s_ & 1) + kx + 4 * half;
         const char* base = xs + ((size_t)(prow * (CC_TW + 2) + pcol) * CC_CK) * 2;
         const bf16x8 fb = cc_join(cc_tr4(base, CC_CK * 2, 16 * sub, lane), cc_tr4(base + 8 * CC_CK * 2, CC_CK * 2, 16 * sub, lane));
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k], fb, acc[tap], 0, 0, 0);
+        acc[tap] = mvit_mfma32(fa[k], fb, acc[tap], 0, 0, 0);
       }
     }
     buf ^= 1;

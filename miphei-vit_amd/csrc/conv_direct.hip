@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const CdArgs p) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const bf16x8 wa = *(const bf16x8*)(Ws + ((size_t)((ky * 3 + kx) * COUT + nt * 32 + l31) * G::WROW + kk * 16 + half * 8) * 2);
-            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[ky], acc[0][nt], 0, 0, 0);
-            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[ky + 1], acc[1][nt], 0, 0, 0);
+            acc[0][nt] = mvit_mfma32(wa, xb[ky], acc[0][nt], 0, 0, 0);
+            acc[1][nt] = mvit_mfma32(wa, xb[ky + 1], acc[1][nt], 0, 0, 0);
           }
         }
       }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const CwArgs 
             const uint4 z = make_uint4(0, 0, 0, 0);
             fb = *(const bf16x8*)&z;
           }
-          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_], fb, acc[a], 0, 0, 0);
+          acc[a] = mvit_mfma32(fa[s_], fb, acc[a], 0, 0, 0);
         }
       }
     }

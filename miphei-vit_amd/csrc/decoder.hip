@@ -14,8 +14,8 @@ __device__ __forceinline__ void unpack8(const uint4& t, float (&f)[8]) {
   const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    f[2 * j] = __uint_as_float(u[j] << 16);
-    f[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+    f[2 * j] = lo16f(u[j]);
+    f[2 * j + 1] = hi16f(u[j]);
   }
 }
 __device__ __forceinline__ uint4 pack8f(const float (&f)[8]) {

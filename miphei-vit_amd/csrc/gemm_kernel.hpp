@@ -377,9 +377,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     if constexpr (EARLY_CONST) load_col_consts(n0);
     auto mfma1 = [](const bf16x8& x, const bf16x8& y, const acc_t& c) __attribute__((always_inline)) {
       if constexpr (MI16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+        return mvit_mfma16(x, y, c, 0, 0, 0);
       else
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+        return mvit_mfma32(x, y, c, 0, 0, 0);
     };
 
     // ---------------------------------------------------------------- main loop
@@ -657,8 +657,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = TRANS ? mvit_mfma32(fb[j], fa[i], acc[i][j], 0, 0, 0)
+                              : mvit_mfma32(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
       cb = cb + 1 == NSTAGE ? 0 : cb + 1;
       ib = ib + 1 == NSTAGE ? 0 : ib + 1;
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
         const uint4 t = *(const uint4*)q;
         const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+        for (int e = 0; e < 4; ++e) o[2 * e] = lo16f(u[e]), o[2 * e + 1] = hi16f(u[e]);
       } else {
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = e < nv ? bf2f(q[e]) : 0.f;
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const mvit
     auto un8bf = [&](const uint4& t, float (&o)[V]) __attribute__((always_inline)) {
       const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+      for (int e = 0; e < 4; ++e) o[2 * e] = lo16f(u[e]), o[2 * e + 1] = hi16f(u[e]);
     };
 
     if constexpr (TRANS) {

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const mvit_gemm_tn_args p)
         const char* bt = b + (jl / 64) * BLK_BYTES;
         const int b_cb = (jl % 64) + 16 * ((lane >> 4) & 1);
         const bf16x8 fb = join(tr_read4(bt, mb, b_cb, lane), tr_read4(bt, mb + 8, b_cb, lane));
-        acc[t] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[t], 0, 0, 0)
-                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+        acc[t] = TR ? mvit_mfma32(fb, fa, acc[t], 0, 0, 0)
+                    : mvit_mfma32(fa, fb, acc[t], 0, 0, 0);
       }
     }
     cur = cur + 1 == NST ? 0 : cur + 1;

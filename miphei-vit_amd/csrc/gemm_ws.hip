@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 #pragma unroll
       for (int m = 0; m < TMc * TN; ++m) {
         const int i = m / TN, j = (SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mvit_mfma16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
         {
 #pragma unroll
           for (int r = 0; r < NR; ++r)      // reads spread over the MFMAs: ceil((m + 1) NR / NM) issued by MFMA m
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 #pragma unroll
       for (int m = 0; m < HO; ++m) {
         const int i = m / TN, j = (SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mvit_mfma16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
 #pragma unroll
       for (int m = HO; m < TMc * TN; ++m) {
         const int i = m / TN, j = (SNAKE && ((m / TN) & 1)) ? TN - 1 - m % TN : m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mvit_mfma16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         if (more) {
           constexpr int NM2 = NM - HO;
 #pragma unroll
@@ -699,8 +699,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
           float da[V], db[V];
 #pragma unroll
           for (int e = 0; e < V; ++e) {
-            const float a_ = (e & 1) ? __uint_as_float(ua[e >> 1] & 0xffff0000u) : __uint_as_float(ua[e >> 1] << 16);
-            const float b_ = (e & 1) ? __uint_as_float(ub[e >> 1] & 0xffff0000u) : __uint_as_float(ub[e >> 1] << 16);
+            const float a_ = (e & 1) ? hi16f(ua[e >> 1]) : lo16f(ua[e >> 1]);
+            const float b_ = (e & 1) ? hi16f(ub[e >> 1]) : lo16f(ub[e >> 1]);
             const float sg = sigmoidf_(a_);
             const float vs = v[e] * sg;
             da[e] = vs * b_ * (1.f + a_ * (1.f - sg));
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws_kernel(const mvit_ge
     auto un8bf = [&](const uint4& tq, float (&o)[V]) __attribute__((always_inline)) {
       const uint32_t u[4] = {tq.x, tq.y, tq.z, tq.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[2 * e] = __uint_as_float(u[e] << 16), o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+      for (int e = 0; e < 4; ++e) o[2 * e] = lo16f(u[e]), o[2 * e + 1] = hi16f(u[e]);
     };
     auto pk8 = [&](const float (&o)[V]) __attribute__((always_inline)) {
       return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));

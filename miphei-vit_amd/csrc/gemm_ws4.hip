@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws4_kernel(const mvit_g
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const int i = m / TN, j = m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mvit_mfma16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < NR; ++r)
           if (r >= (m * NR + NM - 1) / NM && r < ((m + 1) * NR + NM - 1) / NM) read_sub(cur, 1, r, fa[1], fb[1]);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws4_kernel(const mvit_g
 #pragma unroll
       for (int m = 0; m < HO; ++m) {
         const int i = m / TN, j = m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mvit_mfma16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void gemm_ws4_kernel(const mvit_g
 #pragma unroll
       for (int m = HO; m < NM; ++m) {
         const int i = m / TN, j = m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mvit_mfma16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
         if (more) {
           constexpr int NM2 = NM - HO;
 #pragma unroll

@@ -27,8 +27,8 @@ __device__ __forceinline__ void load_x32(const bf16_t* __restrict__ p, float (&x
     const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      x[v * 8 + 2 * j] = __uint_as_float(u[j] << 16);
-      x[v * 8 + 2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+      x[v * 8 + 2 * j] = lo16f(u[j]);
+      x[v * 8 + 2 * j + 1] = hi16f(u[j]);
     }
   }
 }
@@ -39,8 +39,8 @@ __device__ __forceinline__ void load_g16(const bf16_t* __restrict__ p, float (&g
     const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      g[v * 8 + 2 * j] = __uint_as_float(u[j] << 16);
-      g[v * 8 + 2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+      g[v * 8 + 2 * j] = lo16f(u[j]);
+      g[v * 8 + 2 * j + 1] = hi16f(u[j]);
     }
   }
 }
@@ -76,10 +76,10 @@ __device__ __forceinline__ bf16x8 frag_lo(uint32_t w0) {  // K slots 0,1 from on
 // fp32 value as a (hi, lo) bf16 pair packed into one word: hi + lo carries ~16 mantissa bits through a bf16 MFMA
 __device__ __forceinline__ uint32_t split_bf(float v) {
   const uint32_t hi = pack2bf(v, 0.f) & 0xffffu;
-  const float rem = v - __uint_as_float(hi << 16);
+  const float rem = v - lo16f(hi);
   return hi | (pack2bf(rem, 0.f) << 16);
 }
-__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return mvit_mfma32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -112,7 +112,7 @@ __device__ __forceinline__ void frag8_split(const float* f, bf16x8& hi, bf16x8& 
   float h[8], l[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    h[e] = __uint_as_float(pack2bf(f[e], 0.f) << 16);
+    h[e] = lo16f(pack2bf(f[e], 0.f));
     l[e] = f[e] - h[e];
   }
   hi = frag8(h);
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const bf16_t* __restrict__
   __syncthreads();
   char* tile = tiles[wave];
   Frag ones;
-  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = MVIT_ONE2;
   f32x16 acc = zero16(), s = zero16();
   const long long ntile = (M + 31) / 32;
   for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const bf16_t* __restri
     w2s[f][lane] = frag8(v);
   }
   __syncthreads();
-  const bf16x8 ones = frag_lo(half == 0 ? 0x3f803f80u : 0u);
+  const bf16x8 ones = frag_lo(half == 0 ? MVIT_ONE2 : 0u);
   float b2r[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) b2r[j] = b2[min(acc_row(j, half), NH - 1)] * (acc_row(j, half) < NH ? 1.f : 0.f);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const bf16_t* __restrict_
       const uint32_t gu[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w};
       float g[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = __uint_as_float((e & 1) ? (gu[e >> 1] & 0xffff0000u) : (gu[e >> 1] << 16));
+      for (int e = 0; e < 8; ++e) g[e] = ((e & 1) ? hi16f(gu[e >> 1]) : lo16f(gu[e >> 1]));
       char* prow = Ps + (size_t)(wave * 32 + l31) * CF_PS + half * 32;
       int tl = lane;  // opaque per iteration: the operand-table reads stay inside the loop
       asm volatile("" : "+v"(tl));
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void conv_bwd_kernel(const bf16_t* __restri
       if (live) gq = *(const uint4*)(G + (size_t)p * MAXH + half * 8);
       const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = __uint_as_float((e & 1) ? (gu[e >> 1] & 0xffff0000u) : (gu[e >> 1] << 16));
+      for (int e = 0; e < 8; ++e) g[e] = ((e & 1) ? hi16f(gu[e >> 1]) : lo16f(gu[e >> 1]));
     }
     uint4 dzq[9];
 #pragma unroll
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void conv_bwd_kernel(const bf16_t* __restri
           float ev[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float dz = __uint_as_float((e & 1) ? (du[e >> 1] & 0xffff0000u) : (du[e >> 1] << 16));
+            const float dz = ((e & 1) ? hi16f(du[e >> 1]) : lo16f(du[e >> 1]));
             dg[e] += dz * T[8 * dd + e];
             ev[e] = g[e] * dz;
           }
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(512, 1) void gate_bwd_reduce_kernel(const bf16_t* _
         const float dg[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float g = __uint_as_float((e & 1) ? (gu[e >> 1] & 0xffff0000u) : (gu[e >> 1] << 16));
+          const float g = ((e & 1) ? hi16f(gu[e >> 1]) : lo16f(gu[e >> 1]));
           dpsi[e] = (half * 8 + e < NH) ? dg[e] * g * (1.f - g) : 0.f;
         }
       } else {
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_apply_kernel(const bf16_t* __
     frag8_split(f, qh[ks], ql[ks]);
   }
   const uint32_t rw = half == 0 ? split_bf(r[l31]) : 0u;
-  const bf16x8 ones = frag_lo(half == 0 ? 0x3f803f80u : 0u);
+  const bf16x8 ones = frag_lo(half == 0 ? MVIT_ONE2 : 0u);
 
   const long long ntile = (M + 31) / 32;
   for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {

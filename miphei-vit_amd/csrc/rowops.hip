@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * LNL_ROWS) void ln_fwd_lora_kernel(const float*
     for (int ks = wave; ks < nks; ks += 4) {
       const bf16x8 fa = *(const bf16x8*)(ha + ks * 64);
       const bf16x8 fb = *(const bf16x8*)(ab + ks * 64);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+      acc = mvit_mfma16(fa, fb, acc, 0, 0, 0);
     }
     if (wave > 0) {
 #pragma unroll
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(1024) void ln_fwd_lora2_kernel(const float* __restr
       for (int ks = kw; ks < nks; ks += 4) {
         const bf16x8 fa = *(const bf16x8*)(ha + ks * 64);
         const bf16x8 fb = *(const bf16x8*)(ab + ks * 64);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+        acc = mvit_mfma16(fa, fb, acc, 0, 0, 0);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) part[(wave * 64 + lane) * 4 + j] = acc[j];
@@ -340,10 +340,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     if (FULL || idx < nv) {
       if (!accumulate) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      g[i].x *= __uint_as_float(gp[i].x << 16);
-      g[i].y *= __uint_as_float(gp[i].x & 0xffff0000u);
-      g[i].z *= __uint_as_float(gp[i].y << 16);
-      g[i].w *= __uint_as_float(gp[i].y & 0xffff0000u);
+      g[i].x *= lo16f(gp[i].x);
+      g[i].y *= hi16f(gp[i].x);
+      g[i].z *= lo16f(gp[i].y);
+      g[i].w *= hi16f(gp[i].y);
     }
   }
   const float mu = wave_sum(s) / D;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
     for (int u = 0; u < U; ++u) {
       xa[u].x &= xmask, xa[u].y &= xmask, xa[u].z &= xmask, xa[u].w &= xmask;
       wb[u].x &= wmask, wb[u].y &= wmask, wb[u].z &= wmask, wb[u].w &= wmask;
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&xa[u], *(bf16x8*)&wb[u], acc, 0, 0, 0);
+      acc = mvit_mfma16(*(bf16x8*)&xa[u], *(bf16x8*)&wb[u], acc, 0, 0, 0);
     }
   }
   for (; k < K; k += 256) {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void skinny_xw_kernel(const SkinnyPair pr, int
       const bool kok = kk + kq * 8 < K;
       const uint4 xa = (rok && kok) ? *(const uint4*)(xp + kk) : zero;
       const uint4 wb = (wok && kok) ? *(const uint4*)(wp + kk) : zero;
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&xa, *(const bf16x8*)&wb, acc, 0, 0, 0);
+      acc = mvit_mfma16(*(const bf16x8*)&xa, *(const bf16x8*)&wb, acc, 0, 0, 0);
     }
   }
   if (wave > 0) {

@@ -22,6 +22,7 @@ from types import SimpleNamespace as NS
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .ops import (A_CONV3, A_CONV3_T, A_PATCH, ACCUM_BF16, ATOMIC, EPI_DGELU, EPI_DSWIGLU, EPI_GELU, EPI_PATCH, EPI_RESID,
                   EPI_STATS, EPI_STORE, EPI_SWIGLU, OUT_F32, RELU)
@@ -78,6 +79,21 @@ class HipEngine:
         self._pack_key = None
         self._fold_key = None
         self._saved = None
+
+    def operand_mode(self):
+        """"f16" when the module's parameters are fp16 (`generator.eval().cuda().half()`, the reference's evaluation convention,
+        /root/reference/evaluation/eval_orion.py:191, 214-215): the forward then runs on libmiphei_hip_f16.so -- IEEE fp16 operands on
+        v_mfma_f32_*_f16, the weights exactly as the module holds them -- instead of re-rounding them to bf16.  Everything else is
+        the bf16 library.  A change of mode drops every derived cache."""
+        try:
+            p = next(self.model.encoder.vit.parameters())
+        except StopIteration:
+            return "bf16"
+        mode = "f16" if p.dtype == torch.float16 else "bf16"
+        if mode != getattr(self, "_mode_cached", mode):
+            self.invalidate()
+        self._mode_cached = mode
+        return mode
 
     def params_changed(self):
         """The trainable parameters were rewritten in place through the flat buffer (Adam step, a rank-0 broadcast): such writes do not
@@ -231,7 +247,7 @@ class HipEngine:
         dev = self._require_gpu()
         c = self._config()
         vit = self.model.encoder.vit
-        bf = torch.bfloat16
+        bf = L.operand_torch_dtype()
 
         def w16(t):
             return t.detach().to(device=dev, dtype=bf).contiguous()
@@ -296,7 +312,7 @@ class HipEngine:
         key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:4]), need_bwd)
         if self._pack_key == key:
             return self._pack
-        bf = torch.bfloat16
+        bf = L.operand_torch_dtype()
         pk = NS()
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
         fl = self._flat
@@ -357,7 +373,7 @@ class HipEngine:
                 # (packed by ONE launch below, into buffers that persist across steps)
                 bufs = self.__dict__.setdefault("_wch_bufs", {})
                 for dg in ((False, True) if need_bwd else (False,)):
-                    key_ = (i, dg, tuple(w.shape), str(dev))
+                    key_ = (i, dg, tuple(w.shape), str(dev), bf)
                     if key_ not in bufs:
                         bufs[key_] = torch.empty(ops.conv3x3_chunked_pack_elems(w, dg), device=dev, dtype=bf)
                     (pk.wch_b if dg else pk.wch_f)[i] = bufs[key_]
@@ -408,7 +424,7 @@ class HipEngine:
         if key in self._ws:
             return self._ws[key]
         dev = self._require_gpu()
-        bf = torch.bfloat16
+        bf = L.operand_torch_dtype()
         e = lambda *s, dt=bf: torch.empty(*s, device=dev, dtype=dt)
         z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
         M, D, S = B * c.ntok, c.D, c.S
@@ -550,7 +566,7 @@ class HipEngine:
         if not w.ores_on:
             return None
         if w.ores is None:
-            w.ores = [torch.empty(w.M, self._config().D, device=w.tok.device, dtype=torch.bfloat16) for _ in range(len(w.o))]
+            w.ores = [torch.empty(w.M, self._config().D, device=w.tok.device, dtype=L.operand_torch_dtype()) for _ in range(len(w.o))]
         return w.ores[i]
 
     def _encoder_fwd(self, w, x, train, pk, taps=None, img8=None):
@@ -562,7 +578,7 @@ class HipEngine:
         dp = w.dpath
         P = c.grid * c.grid
         if img8 is not None:
-            if img8.dtype != torch.bfloat16 or tuple(img8.shape) != tuple(w.img8.shape) or not img8.is_contiguous():
+            if img8.dtype != L.operand_torch_dtype() or tuple(img8.shape) != tuple(w.img8.shape) or not img8.is_contiguous():
                 raise ValueError(f"img8: expected a contiguous bf16 tensor {tuple(w.img8.shape)}")
             im8 = img8            # read in place (the decoder and its backward use the same buffer)
         else:
@@ -734,6 +750,14 @@ class HipEngine:
         """Generator forward.  train=True keeps the activations the backward pass needs (one graph in flight).
         img8: optional bf16 NHWC [B,S,S,8] copy of x (channels 3..7 zero) as the input stage writes it; replaces the engine's own
         NCHW -> NHWC conversion of the decoder's image operand."""
+        mode = self.operand_mode()
+        if mode == "f16" and train:
+            raise RuntimeError("training needs fp32 master parameters (do not call .half() on a model that trains): the fp16 operand "
+                               "library is the evaluation convention generator.eval().cuda().half()")
+        with L.operands(mode):
+            return self._forward(x, train, bn_train, img8)
+
+    def _forward(self, x, train, bn_train, img8):
         dev = self._require_gpu()
         c = self._config()
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != c.S or x.shape[3] != c.S:
@@ -1100,7 +1124,8 @@ def encoder_tokens(vit, x):
     c = eng._config()
     if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != c.S or x.shape[3] != c.S:
         raise ValueError(f"expected [B,3,{c.S},{c.S}] input, got {tuple(x.shape)}")
-    pk = eng._pack_trainable(need_bwd=False)
-    w = eng._workspace(x.shape[0], False)
-    tok = eng._encoder_fwd(w, x, False, pk)
-    return tok.view(x.shape[0], c.ntok, c.D).float()
+    with L.operands(eng.operand_mode()):       # fp16 parameters (`.half()`): the fp16-operand library
+        pk = eng._pack_trainable(need_bwd=False)
+        w = eng._workspace(x.shape[0], False)
+        tok = eng._encoder_fwd(w, x, False, pk)
+        return tok.view(x.shape[0], c.ntok, c.D).float()

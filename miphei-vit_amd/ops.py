@@ -83,8 +83,9 @@ def _p(t):
 
 
 def _chk_bf16(t, name):
-    if t.dtype != torch.bfloat16 or not t.is_cuda:
-        raise TypeError(f"{name}: expected a CUDA bfloat16 tensor, got {t.dtype} on {t.device}")
+    """16-bit operand tensor of the current operand mode (bf16; fp16 inside `_lib.operands("f16")`)"""
+    if t.dtype != L.operand_torch_dtype() or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA {L.operand_torch_dtype()} tensor, got {t.dtype} on {t.device}")
 
 
 def gemm(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, a2=None, b2=None, K2=0, bias=None,
@@ -412,7 +413,7 @@ def pack_conv3x3_direct(W, n_out, k_pad, rot=0, dgrad=False):
     cout, cin = W.shape[0], W.shape[1]
     k_in = cout if dgrad else cin
     wrow = (k_pad + 15) // 16 * 16 + 8
-    out = torch.empty(9, n_out, wrow, device=W.device, dtype=torch.bfloat16)
+    out = torch.empty(9, n_out, wrow, device=W.device, dtype=L.operand_torch_dtype())
     _call("mvit_pack_conv3x3_direct", _p(W), _p(out), cout, cin, n_out, k_in, k_pad, rot, int(dgrad))
     return out
 
@@ -434,7 +435,7 @@ def pack_conv3x3_chunked(W, dgrad=False):
     assert W.dtype == torch.float32 and W.is_contiguous()
     cout, cin = W.shape[0], W.shape[1]
     n, k = (cin, cout) if dgrad else (cout, cin)
-    out = torch.empty(int(L.lib().mvit_conv3x3_chunked_pack_elems(n, k)), device=W.device, dtype=torch.bfloat16)
+    out = torch.empty(int(L.lib().mvit_conv3x3_chunked_pack_elems(n, k)), device=W.device, dtype=L.operand_torch_dtype())
     _call("mvit_conv3x3_chunked_pack", _p(W), _p(out), cout, cin, int(dgrad))
     return out
 
@@ -450,7 +451,7 @@ def pack_conv3x3_chunked_multi(items):
     n = len(items)
     arr = (L.CcPackDesc * n)()
     for i, (W, out, dgrad) in enumerate(items):
-        assert W.dtype == torch.float32 and W.is_contiguous() and out.dtype == torch.bfloat16
+        assert W.dtype == torch.float32 and W.is_contiguous() and out.dtype == L.operand_torch_dtype()
         assert out.numel() >= conv3x3_chunked_pack_elems(W, dgrad)
         arr[i].W, arr[i].out, arr[i].Cout, arr[i].Cin, arr[i].mode = W.data_ptr(), out.data_ptr(), W.shape[0], W.shape[1], int(dgrad)
     L.check(L.lib().mvit_conv3x3_chunked_pack_multi(arr, n, _stream()), "mvit_conv3x3_chunked_pack_multi")

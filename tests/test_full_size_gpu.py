@@ -134,6 +134,35 @@ def test_hoptimus0_batch16_tiles_agree_with_batch2_chunks(B):
     assert float(rel.max()) < 2e-4, rel     # both are bf16 paths: different tile shapes = different summation order only
 
 
+def test_hoptimus0_half_precision_eval_forward_vs_oracle():
+    """The reference's evaluation convention at the full model size: generator.eval().cuda().half() on x.half()
+    (/root/reference/evaluation/eval_orion.py:191, 214-215) runs on the fp16-operand library (v_mfma_f32_*_f16); output vs the fp32 CPU
+    oracle on the fp32 parameters within the north-star tolerance, and closer to it than the bf16-operand forward of the same module."""
+    import bench
+    from oracle import VIT_CONFIGS, generator_forward
+    from miphei_vit_amd.generators import get_vitmatte
+    nc, img, B = 16, 256, 2
+    dev = torch.device("cuda:0")
+    with torch.device(dev):
+        model = get_vitmatte("hoptimus0", img, nc, use_lora=True, pretrained=False)
+    bench.synthetic_init_(model, seed=9)
+    model.eval()
+    x, _ = bench.synthetic_batch(31, B, img, nc, dev)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    p = {k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        out_bf = model(x).float().cpu()
+        ref = generator_forward(p, x.cpu(), VIT_CONFIGS["hoptimus0"], nc, training=False)
+        model.half()
+        assert model._engine.operand_mode() == "f16"
+        out = model(x.half())
+    assert out.dtype == torch.float16 and torch.isfinite(out).all()
+    rel = lambda a: float((((a - ref) ** 2).sum(dim=(0, 2, 3)) / (ref ** 2).sum(dim=(0, 2, 3))).max())
+    e16, ebf = rel(out.float().cpu()), rel(out_bf)
+    print(f"worst-channel relative MSE vs the fp32 oracle: fp16 operands {e16:.3e}, bf16 operands {ebf:.3e}")
+    assert e16 < 1e-3 and e16 < ebf, (e16, ebf)
+
+
 def test_hoptimus0_batch64_hipgraph_replay_equals_eager():
     """BASELINE configs[4] at size: the hipGraph-captured batch-64 forward of H-Optimus-0 at 256 x 256 (merged LoRA, eval-mode
     BatchNorm, the 256 x 256 / wave-specialised GEMM tiles of the inference path) returns exactly the eager result, for two

@@ -16,16 +16,20 @@ def test_library_exports_every_declared_symbol():
     """Every MVIT_API function of include/miphei_hip.h is exported by the built library and bound by ctypes."""
     import __graft_entry__ as g
     from miphei_vit_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.LIB_PATH_F16)):
         g.build()
     hdr = open(os.path.join(ROOT, "include", "miphei_hip.h")).read()
     declared = set(re.findall(r"MVIT_API\s+(?:int|long long)\s+(mvit_\w+)\s*\(", hdr))
     assert len(declared) >= 30
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    handle = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(handle, name), name
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_F16):        # the bf16-operand library and its fp16-operand twin export the same ABI
+        handle = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(handle, name), (path, name)
     _lib.lib()
+    with _lib.operands("f16"):
+        assert _lib.lib() is not _lib._libs["bf16"] and _lib.operand_torch_dtype() == torch.float16
+    assert _lib.operand_mode() == "bf16" and _lib.operand_torch_dtype() == torch.bfloat16
     # struct layout of mvit_gemm_args matches the C definition (pointers first, then ints, 8-byte aligned)
     body = hdr[hdr.index("typedef struct mvit_gemm_args"):hdr.index("} mvit_gemm_args;")]
     n_ptr = len(re.findall(r"\*\s*\w+\s*[;,]", body))

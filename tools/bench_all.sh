@@ -11,7 +11,8 @@ run bench_train                                                                 
 run bench_train_metrics_on --metrics 1 --no-cpu-baseline
 run bench_infer_b64_hipgraph --mode infer --batch 64 --steps 20 --warmup 5         # configs[4]: tiles/s + p50 batch latency
 run bench_train_512_b4 --img 512 --batch 4 --steps 10 --warmup 3 --no-cpu-baseline # configs[3], 1 GPU
-run bench_embed_b64 --mode embed --batch 64 --steps 20 --warmup 5
+run bench_embed_b64 --mode embed --batch 64 --steps 20 --warmup 5                  # SURVEY 8f row 4 (fp16 operands: the reference's .half())
+run bench_infer_b64_hipgraph_fp16 --mode infer --batch 64 --steps 20 --warmup 5 --dtype fp16   # configs[4] under generator.eval().cuda().half()
 run bench_unetr_train --generator unet_lora --no-cpu-baseline --steps 10 --warmup 3
 run bench_unetr_infer_b64 --generator unet_lora --mode infer --batch 64 --steps 10 --warmup 3
 MIPHEI_FORCE_DDP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 \
