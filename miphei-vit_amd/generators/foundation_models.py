@@ -168,10 +168,35 @@ def _build(img_size, pretrained, ckpt_path, name, drop_path_rate=0., **kw):
     if ckpt_path is not None:
         _load_checkpoint(model, ckpt_path, img_size)
     elif pretrained and os.environ.get("MIPHEI_RANDOM_INIT", "0") != "1":
-        raise RuntimeError(
-            f"{name}: no checkpoint given (cfg.model.encoder.encoder_weights) and the Hugging Face hub is not reachable; "
-            "pass ckpt_path, or pretrained=False / MIPHEI_RANDOM_INIT=1 for randomly initialised weights")
+        _load_checkpoint(model, _hub_checkpoint(name), img_size)
     return model
+
+
+# hub ids of the pretrained encoders (reference foundation_models.py:13-21; only the encoder on the hot path is kept)
+FOUNDATION_HF_CKPT_REGISTRY = {"hoptimus0": "bioptimus/H-optimus-0"}
+
+
+def _hub_checkpoint(name):
+    """Local path of the pretrained weights of registry model `name`, fetched from the Hugging Face hub or its local cache as the
+    reference does through timm's `load_state_dict_from_hf(model_id, weights_only=True)` (/root/reference/src/generators/
+    foundation_models.py:59-64): `model.safetensors` first, then `pytorch_model.bin`.  Honours HF_HUB_OFFLINE / HF_HOME.  A box without
+    network access and without a cached copy fails loudly, naming the ways out -- never silent random weights."""
+    repo = FOUNDATION_HF_CKPT_REGISTRY.get(name)
+    errors = []
+    if repo is not None:
+        try:
+            from huggingface_hub import hf_hub_download
+            for fname in ("model.safetensors", "pytorch_model.bin"):
+                try:
+                    return hf_hub_download(repo_id=repo, filename=fname)
+                except Exception as e:  # noqa: BLE001  (missing file, gated repo, no network: try the next name, then report all)
+                    errors.append(f"{fname}: {type(e).__name__}: {str(e).splitlines()[0][:160] if str(e) else ''}")
+        except ImportError as e:
+            errors.append(f"huggingface_hub: {e}")
+    raise RuntimeError(
+        f"{name}: no checkpoint given (cfg.model.encoder.encoder_weights) and the pretrained weights could not be fetched from the "
+        f"Hugging Face hub ({repo or 'no hub id for this encoder'}; {'; '.join(errors) or 'not attempted'}); pass ckpt_path, put the "
+        "repository into the local hub cache (HF_HOME), or use pretrained=False / MIPHEI_RANDOM_INIT=1 for randomly initialised weights")
 
 
 def hoptimus0(img_size, pretrained=True, ckpt_path=None, drop_path_rate=0., global_pool=""):

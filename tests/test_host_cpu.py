@@ -338,3 +338,33 @@ def test_shuffled_indices_are_epoch_permutations_shared_by_all_ranks():
     two = torch.cat([torch.cat([shuffled_indices((i * 2 + r) * B, B, N, 3) for r in range(2)]) for i in range(6)])
     assert torch.equal(one, two)
     assert torch.equal(one[:N], e0) and torch.equal(one[N:2 * N], e1)
+
+
+def test_pretrained_encoder_comes_from_the_hub_or_fails_loudly(tmp_path, monkeypatch):
+    """get_vitmatte(..., pretrained=True) without a ckpt_path (reference foundation_models.py:59-64: timm's load_state_dict_from_hf):
+    the weights are fetched through huggingface_hub (model.safetensors, then pytorch_model.bin) and loaded; without network and
+    without a cached copy the factory raises, naming the hub id and the ways out -- never silent random weights."""
+    import huggingface_hub
+    from safetensors.torch import save_file
+    from miphei_vit_amd.generators import foundation_models as fm
+
+    def no_network(repo_id, filename, **kw):
+        raise OSError(f"offline: cannot reach the hub for {repo_id}/{filename}")
+    monkeypatch.setattr(huggingface_hub, "hf_hub_download", no_network)
+    monkeypatch.delenv("MIPHEI_RANDOM_INIT", raising=False)
+    with pytest.raises(RuntimeError, match="bioptimus/H-optimus-0"):
+        fm._hub_checkpoint("hoptimus0")
+    with pytest.raises(RuntimeError, match="no hub id"):
+        fm._hub_checkpoint("tiny")
+    # a hub that answers: the downloaded file is what the model ends up with (tiny encoder standing in for the 1.1 B one)
+    src = fm.tiny_gelu(128)
+    sd = {k: torch.randn_like(v) for k, v in src.state_dict().items()}
+    path = str(tmp_path / "model.safetensors")
+    save_file(sd, path)
+    seen = []
+    monkeypatch.setattr(huggingface_hub, "hf_hub_download", lambda repo_id, filename, **kw: seen.append((repo_id, filename)) or path)
+    monkeypatch.setitem(fm.FOUNDATION_HF_CKPT_REGISTRY, "tiny", "someone/tiny-vit")
+    got = fm._build(128, True, None, "tiny", patch_size=16, embed_dim=64, depth=2, num_heads=4, mlp="gelu", hidden=256, reg_tokens=4,
+                    init_values=1e-5, global_pool="")
+    assert seen == [("someone/tiny-vit", "model.safetensors")]
+    assert all(torch.equal(v, sd[k]) for k, v in got.state_dict().items())
