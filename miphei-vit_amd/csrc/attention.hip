@@ -850,7 +850,7 @@ __device__ __forceinline__ void issue_pieces(const TileIssue& ti, char* RING, in
 
 template <bool FAST, bool KMASK>
 __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, int lane, const Ptrs& P, const AttnDims& dm, size_t rs,
-                                         const TileIssue& tp, int bh) {
+                                         const TileIssue& tp, int bh, const uint4 (&kraw)[3][2], const uint4 (&vraw)[3][2]) {
   FST_DECL
   const int l15 = lane & 15, g = lane >> 4, N = dm.N;
   char* DS = smem + NKR * 128;
@@ -884,7 +884,8 @@ __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, 
     }
   };
 
-  // resident K / V fragments: B operand (column = key 48 w + 16 kt + l15, k = d = 32 ks + 8 g ..)
+  // resident K / V fragments: B operand (column = key 48 w + 16 kt + l15, k = d = 32 ks + 8 g ..), requested by the kernel's first
+  // instructions (frag_loads), ahead of the K-row and tile DMA
   bf16x8 kf[3][2], vf[3][2];
   float cinit[3];
 #pragma unroll
@@ -892,15 +893,7 @@ __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, 
     const int key = KW * wave + 16 * kt + l15;
     cinit[kt] = key < N ? 0.f : -1e30f;      // S of a padding key starts at -1e30: P = exp2(-1e30 sc - L) = 0 with no masking instruction
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 t = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
-      if (key < N) {
-        t = *(const uint4*)(P.kb + (size_t)key * rs + 32 * ks + 8 * g);
-        u = *(const uint4*)(P.vb + (size_t)key * rs + 32 * ks + 8 * g);
-      }
-      kf[kt][ks] = *(bf16x8*)&t;
-      vf[kt][ks] = *(bf16x8*)&u;
-    }
+    for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = *(const bf16x8*)&kraw[kt][ks], vf[kt][ks] = *(const bf16x8*)&vraw[kt][ks];
   }
   f32x4 dk[4][3], dv[4][3];
 #pragma unroll
@@ -1196,6 +1189,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   P.dq = dqkv + (size_t)b * N * rs + (size_t)h * 64;
   P.lse = lse;
   P.Dv = Dv;
+  // key waves: the K / V fragment loads are the kernel's first memory instructions (the prologue is an HBM burst: 256 CUs x 145 KB;
+  // behind the 5-6 K-row DMA pieces and two tile pieces per wave they left ~1000 cycles later)
+  uint4 kraw[3][2], vraw[3][2];
+  if (wave != NKW) {
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int key = KW * wave + 16 * kt + l15;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kraw[kt][ks] = make_uint4(0, 0, 0, 0), vraw[kt][ks] = make_uint4(0, 0, 0, 0);
+        if (key < N) {
+          kraw[kt][ks] = *(const uint4*)(P.kb + (size_t)key * rs + 32 * ks + 8 * g);
+          vraw[kt][ks] = *(const uint4*)(P.vb + (size_t)key * rs + 32 * ks + 8 * g);
+        }
+      }
+    }
+  }
   // K rows -> LDS for the helper's K^T fragments (all waves share the 1 KB pieces): 8-byte slot s of key k at s ^ (h(k) << 2)
   {
     const __amdgpu_buffer_rsrc_t rK = make_rsrc(P.kb);
@@ -1222,19 +1233,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   tp.P = &P, tp.rs = rs, tp.ors = ors, tp.wave = wave, tp.NW = NW;
   issue_pieces<FAST>(tp, RING, 0, N, lane);
   if (NQ > 1) issue_pieces<FAST>(tp, RING, 1, N, lane);
-  // group 0 = the first half of the workgroup's waves, group 1 = the second half incl. the helper: waves i and i + 4 share a SIMD at 8 waves
   if (wave == NKW) {
-    // the helper is the youngest wave of its SIMD and the step's critical path (D, then all of W): without priority it loses every
-    // issue arbitration to the key wave beside it (priority outranks age): 67 -> 59 k cycles per pair
-#ifndef MVIT_FUSED_HPRIO
-#define MVIT_FUSED_HPRIO 3
-#endif
-    __builtin_amdgcn_s_setprio(MVIT_FUSED_HPRIO);
+    // the helper is the youngest wave of its SIMD: with priority it does not lose every issue arbitration to the key wave beside it
+    // (priority outranks age; 67 -> 59 k cycles per pair while it also formed D; 65.1 / 64.1 / 63.2 us at priority 0 / 1 / 3 since)
+    __builtin_amdgcn_s_setprio(3);
     helper_wave<FAST>(smem, NKR, NQ, wave, lane, P, dm, rs, ors, bh, tp);
   } else if (KW * (wave + 1) > N) {
-    key_wave<FAST, true>(smem, NKR, NQ, wave, lane, P, dm, rs, tp, bh);
+    key_wave<FAST, true>(smem, NKR, NQ, wave, lane, P, dm, rs, tp, bh, kraw, vraw);
   } else {
-    key_wave<FAST, false>(smem, NKR, NQ, wave, lane, P, dm, rs, tp, bh);
+    key_wave<FAST, false>(smem, NKR, NQ, wave, lane, P, dm, rs, tp, bh, kraw, vraw);
   }
 }
 }  // namespace fused
