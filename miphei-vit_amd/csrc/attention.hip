@@ -981,8 +981,15 @@ __device__ __forceinline__ void key_wave(char* smem, int NKR, int NQ, int wave, 
     FST(3)
   };
 
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                                            // K rows, step tiles 0 / 1, L are in LDS
+  if (FAST) {
+    if (wave < 4)
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                                            // step tiles 0 / 1 and L are in LDS (not FAST: the K rows too)
   if (FAST && wave < 4) {
     d_rows(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1131,18 +1138,27 @@ __device__ __forceinline__ void helper_wave(char* smem, int NKR, int NQ, int wav
     FST(3)
   };
   for (int i = lane; i < NQP; i += 64) LD[i] = i < N ? P.lse[(size_t)bh * N + i] * LOG2E : 1e30f;   // padding rows: P = exp2(.. - 1e30) = 0
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                                  // every wave's share of the K rows and of tiles 0 / 1 is in LDS
+  if (FAST) {
+    if (wave < 4)
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                                  // every wave's share of tiles 0 / 1 is in LDS (not FAST: of the K rows too)
   if (!FAST) d_block(0);                                         // (FAST: key waves 0-3 form D)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   FST(0)
-  // step 0: the K^T fragments instead of a dQ product
+  // step 0 has no dQ product: the K^T fragments are read instead -- FAST: after step 0's barrier, behind which every wave's K pieces
+  // have landed (NQ == 1: right behind the loop)
   if (2 < NQ) issue_pieces<FAST>(tp, RING, 2, N, lane);
   if (!FAST && NQ > 1) d_block(1);
-  load_afr();
+  if (!FAST) load_afr();
   FST(1)
   bar();
+  if (FAST) load_afr();
   int j = 1;
   for (; j + 2 < NQ; ++j) {                                      // steady state: one basic block, so that the scheduler can put D's vector
     issue_pieces<FAST>(tp, RING, j + 2, N, lane);                      // work between the MFMAs of W
@@ -1207,8 +1223,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
       }
     }
   }
-  // K rows -> LDS for the helper's K^T fragments (all waves share the 1 KB pieces): 8-byte slot s of key k at s ^ (h(k) << 2)
+  // step tiles 0 and 1
+  char* RING = smem + NKR * 256;
+  TileIssue tp;
+  tp.tp = tile_pieces(wave, lane, P, rs, ors);
+  tp.P = &P, tp.rs = rs, tp.ors = ors, tp.wave = wave, tp.NW = NW;
+  issue_pieces<FAST>(tp, RING, 0, N, lane);
+  if (NQ > 1) issue_pieces<FAST>(tp, RING, 1, N, lane);
   {
+    // rows of the dS^T buffers that no key wave writes (keys NKW * 48 .. NKR - 1): zero once, they are multiplied with zero K rows
+    char* DS = smem + NKR * 128;
+    const int pad0 = NKW * KW * 64, padn = (NKR - NKW * KW) * 64;
+    for (int i = tid * 16; i < padn; i += 512 * 16) {
+      *(uint4*)(DS + pad0 + i) = make_uint4(0, 0, 0, 0);
+      *(uint4*)(DS + NKR * 64 + pad0 + i) = make_uint4(0, 0, 0, 0);
+    }
+    // K rows -> LDS for the helper's K^T fragments (all waves share the 1 KB pieces): 8-byte slot s of key k at s ^ (h(k) << 2).  LAST:
+    // nothing needs them before the helper's fragment loads in step 1, so (FAST) the first barrier does not wait for them -- each
+    // wave's pieces are covered by its vmcnt(0) in front of step 0's barrier
     const __amdgpu_buffer_rsrc_t rK = make_rsrc(P.kb);
     for (int m = wave; m < NKR / 8; m += NW) {
       const int row = 8 * m + (lane >> 3);
@@ -1218,21 +1250,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
       asm volatile("" : "+v"(off));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_ptr)(smem + m * 1024), 16, off, 0, 0, 0);
     }
-    // rows of the dS^T buffers that no key wave writes (keys NKW * 48 .. NKR - 1): zero once, they are multiplied with zero K rows
-    char* DS = smem + NKR * 128;
-    const int pad0 = NKW * KW * 64, padn = (NKR - NKW * KW) * 64;
-    for (int i = tid * 16; i < padn; i += 512 * 16) {
-      *(uint4*)(DS + pad0 + i) = make_uint4(0, 0, 0, 0);
-      *(uint4*)(DS + NKR * 64 + pad0 + i) = make_uint4(0, 0, 0, 0);
-    }
   }
-  // step tiles 0 and 1
-  char* RING = smem + NKR * 256;
-  TileIssue tp;
-  tp.tp = tile_pieces(wave, lane, P, rs, ors);
-  tp.P = &P, tp.rs = rs, tp.ors = ors, tp.wave = wave, tp.NW = NW;
-  issue_pieces<FAST>(tp, RING, 0, N, lane);
-  if (NQ > 1) issue_pieces<FAST>(tp, RING, 1, N, lane);
   if (wave == NKW) {
     // the helper is the youngest wave of its SIMD: with priority it does not lose every issue arbitration to the key wave beside it
     // (priority outranks age; 67 -> 59 k cycles per pair while it also formed D; 65.1 / 64.1 / 63.2 us at priority 0 / 1 / 3 since)
