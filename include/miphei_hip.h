@@ -10,7 +10,8 @@
  *  - plain pointers are DEVICE pointers borrowed from the caller (torch tensors); nothing is
  *    allocated, freed or synchronised inside, and every launch goes to the hipStream_t passed
  *    as `stream` (a void* holding torch.cuda.current_stream().cuda_stream) -> hipGraph-capturable.
- *  - bf16 tensors are raw uint16 bit patterns; "f32" is IEEE float; row-major unless stated.
+ *  - "bf16" tensors are raw uint16 bit patterns: bf16 in libmiphei_hip.so; the same sources built with -DMVIT_F16 (libmiphei_hip_f16.so,
+ *    the reference's evaluation convention generator.eval().cuda().half()) read and write IEEE fp16 in the same places; "f32" is IEEE float; row-major unless stated.
  *  - return 0 on success, a hipError_t value or MVIT_EINVAL (-1) for bad arguments.
  *  - thread-compatible: no global mutable state.
  */
@@ -157,7 +158,11 @@ MVIT_API int mvit_scale_cols_cast(const float* x, const float* gamma, void* out_
  * src/generators/foundation_models.py:53-57; q,v carry LoRA deltas from src/generators/lora.py:29-33). */
 MVIT_API int mvit_attention_fwd(const void* qkv, void* out, void* out_res, float* lse, int B, int N, int H, int Dh, float scale,
                                 mvit_stream_t stream);
-/* dqkv(bf16)[B,N,3,H,Dh] from d_out(bf16)[B,N,H*Dh]; dsum(f32)[B,H,N] is caller-provided scratch; out_res may be NULL. */
+/* dqkv(bf16)[B,N,3,H,Dh] from d_out(bf16)[B,N,H*Dh]: the backward of the call above (loss.backward() through timm's Attention;
+ * the q and v gradients feed the LoRA adapters, src/generators/lora.py:29-33).  dsum(f32)[B,H,N] is caller-provided and receives
+ * D = sum_d dO * (out + out_res); out_res may be NULL (D from the bf16 out alone).  Dh = 64 and N <= 336: ONE launch, one workgroup per
+ * (batch, head) pair, dQ reduced inside the workgroup in a fixed order (round 6); otherwise two launches (dQ, then dK / dV).  Either
+ * way bit-identical from run to run: no atomics. */
 MVIT_API int mvit_attention_bwd(const void* qkv, const void* out, const void* out_res, const void* d_out, const float* lse,
                                 float* dsum, void* dqkv, int B, int N, int H, int Dh, float scale, mvit_stream_t stream);
 
