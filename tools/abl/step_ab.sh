@@ -1,5 +1,7 @@
 #!/bin/bash
 # same-box, interleaved A/B of the training step: library A (MIPHEI_LIB path, default the saved HEAD build) vs the working tree's product library
+# (library A is a build of an OLDER commit -- git worktree add /tmp/base <commit>; make -C /tmp/base/miphei-vit_amd/csrc LIB=<repo>/miphei-vit_amd/csrc/variants/libmiphei_base.so --
+#  and variant libraries do not travel by default: take the csrc/variants/ line out of .gpurunignore for the call)
 cd $GRAFT_REPO_ROOT
 A=${1:-miphei-vit_amd/csrc/variants/libmiphei_base.so}
 O=gpurun_out/step_ab; mkdir -p $O; : > $O/log.txt
